@@ -1,0 +1,146 @@
+"""Pin the CPU oracle against the golden vectors captured from the real reference
+(tests/golden/make_golden.py): NNs.so outputs, LAPACK eigen-decompositions, the
+reference's own rank lists / cut rows on real instances, and the published fig. 8 data."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import BOXQP_TAGS, GOLDEN, POINTS, agg_from_arrays, golden_nn
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_nn_restatement_bit_identical_to_NNs_so(oracle, k):
+    g = golden_nn(k)
+    y = oracle.nn_batch(k, g["inputs"])
+    assert np.array_equal(y, g["nn_out"])            # bit-exact, 4096 inputs per net
+    # scalar compat entry points (the reference's own calling pattern)
+    for i in (0, 1, 17, 4095):
+        assert oracle.nn_scalar(k, g["inputs"][i]) == g["nn_out"][i]
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_eigmin_batch_matches_per_matrix_lapack(oracle, k):
+    g = golden_nn(k)
+    lam = oracle.eigmin_batch(k, g["x"], g["X"])
+    assert np.array_equal(lam, g["eigvals"][:, 0])
+    w, v = oracle.get_eigendecomp(k, g["x"][5], g["X"][5], True)
+    # eigh and eigvalsh use different LAPACK drivers: values agree to rounding only
+    assert np.allclose(w, g["eigvals"][5], rtol=0, atol=1e-14)
+    assert np.array_equal(v[:, 0], g["evec_min"][5])
+
+
+@pytest.mark.parametrize("tag", BOXQP_TAGS)
+def test_candidate_records(oracle, golden_boxqp, tag):
+    g = golden_boxqp
+    agg = agg_from_arrays(oracle, g[tag + "_set_inds"], g[tag + "_k"], int(g[tag + "_nb_vars"]),
+                          g[tag + "_Q_arr"])
+    assert np.array_equal(np.array([e[3] for e in agg]), g[tag + "_max_elem"])
+
+
+@pytest.mark.parametrize("tag", BOXQP_TAGS)
+@pytest.mark.parametrize("point", POINTS)
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_rank_lists_and_cut_rows_match_reference(oracle, golden_boxqp, tag, point, strat):
+    g = golden_boxqp
+    n = int(g[tag + "_nb_vars"])
+    L = n * (n + 1) // 2
+    agg = agg_from_arrays(oracle, g[tag + "_set_inds"], g[tag + "_k"], n, g[tag + "_Q_arr"])
+    vv = g["%s_%s_vars" % (tag, point)]
+    sel = int(g[tag + "_sel_size"])
+    q = "%s_%s_s%d" % (tag, point, strat)
+    res = oracle.sel_eigcut_by_ordering_on_measure(agg, L, strat, vv, sel_size=sel if strat == 4 else 0)
+    new_strat, rl = res if strat == 4 else (strat, res)
+    assert new_strat == int(g[q + "_new_strat"])
+    if strat == 1:
+        key = {tuple(e[0]): i for i, e in enumerate(agg)}
+        ids = np.array([key[tuple(e[0])] for e in rl], dtype=np.int64)
+    else:
+        ids = np.array([e[0] for e in rl], dtype=np.int64)
+    assert np.array_equal(ids, g[q + "_order"])
+    assert np.array_equal(np.array([e[1] for e in rl], dtype=np.float64), g[q + "_score"])
+    nb, rows, rhs, senses = oracle.gen_eigcuts_selected(agg, L, strat, sel, rl, vars_values=vv)
+    assert nb == int(g[q + "_nb_cuts"])
+    ptr = np.cumsum([0] + [len(r[0]) for r in rows])
+    assert np.array_equal(ptr, g[q + "_row_ptr"])
+    if rows:
+        assert np.array_equal(np.concatenate([r[0] for r in rows]), g[q + "_row_ind"])
+        assert np.array_equal(np.concatenate([r[1] for r in rows]), g[q + "_row_val"])
+    assert np.array_equal(np.array(rhs, dtype=np.float64), g[q + "_rhs"])
+    assert all(s == "G" for s in senses)
+
+
+@pytest.mark.parametrize("tag", BOXQP_TAGS)
+@pytest.mark.parametrize("point", POINTS)
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_array_form_ranking_equals_literal_scan(oracle, golden_boxqp, tag, point, strat):
+    """rank_arrays (closed form used for large N) == the reference's sequential scan."""
+    g = golden_boxqp
+    n = int(g[tag + "_nb_vars"])
+    L = n * (n + 1) // 2
+    S, ks = g[tag + "_set_inds"], g[tag + "_k"]
+    vv = g["%s_%s_vars" % (tag, point)]
+    N = S.shape[0]
+    obj, lam = np.zeros(N), np.zeros(N)
+    for k in np.unique(ks):
+        sel = np.nonzero(ks == k)[0]
+        si = S[sel, :k]
+        obj[sel] = oracle.opt_score_batch(int(k), si, n, vv, g[tag + "_Q_arr"])
+        pos = oracle.triu_positions(si, n)
+        lam[sel] = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][pos])
+    sel_size = int(g[tag + "_sel_size"])
+    order, score, new_strat, _ = oracle.rank_arrays(strat, obj, lam, sel_size)
+    q = "%s_%s_s%d" % (tag, point, strat)
+    assert np.array_equal(order, g[q + "_order"])
+    assert np.array_equal(score, g[q + "_score"])
+    assert new_strat == int(g[q + "_new_strat"])
+
+
+def test_fig8_published_scores_round1(oracle, golden_boxqp):
+    """data_figures/fig8_data.csv round 1: per-candidate NN optimality scores of
+    spar020-100-1 (dim 3) at the McCormick optimum, their order and the top-100 flags."""
+    rows = np.loadtxt(os.path.join(GOLDEN, "fig8_round1.csv"), delimiter=",", skiprows=1)
+    assert rows.shape == (1051, 6)
+    g, tag = golden_boxqp, "spar020_100_1_d3"
+    n = int(g[tag + "_nb_vars"])
+    vv = g[tag + "_mck_vars"]
+    obj = oracle.opt_score_batch(3, g[tag + "_set_inds"][:, :3], n, vv, g[tag + "_Q_arr"])
+    order, score, _, _ = oracle.rank_arrays(2, obj, None, 0)
+    pub_ids, pub_score = rows[:, 1].astype(np.int64), rows[:, 4]
+    assert np.allclose(score, pub_score, rtol=1e-9, atol=1e-11)
+    # identical ordering up to exact ties in the published scores
+    assert np.array_equal(np.sort(order[:100]), np.sort(pub_ids[:100]))
+    assert np.array_equal(rows[:, 2], (np.arange(1051) < 100).astype(float))
+    same = order == pub_ids
+    for i in np.nonzero(~same)[0]:
+        assert abs(pub_score[i] - obj[pub_ids[i]]) <= 1e-9 * max(1.0, abs(pub_score[i]))
+
+
+@pytest.mark.parametrize("strat", [1, 2, 4])
+@pytest.mark.parametrize("sel", [1, 7, 40])
+def test_qcqp_composition(oracle, golden_qcqp, strat, sel):
+    g = golden_qcqp
+    n = int(g["nb_vars"])
+    L = n * (n + 1) // 2
+    agg_o = agg_from_arrays(oracle, g["obj_set_inds"], g["obj_k"], n, g["Q_arr"])
+    agg_c = agg_from_arrays(oracle, g["cons_set_inds"], g["cons_k"], n, g["Q_arr"])
+    r = oracle.qcqp_round(agg_o, agg_c, L, strat, g["vars"], sel)
+    q = "s%d_sel%d" % (strat, sel)
+    assert r["new_strat"] == int(g[q + "_new_strat"])
+    assert np.array_equal(np.array([isinstance(e[0], int) for e in r["rank_list"]]), g[q + "_is_obj"])
+    assert np.array_equal(np.array([e[1] for e in r["rank_list"]], dtype=np.float64), g[q + "_score"])
+    if strat != 1:
+        assert r["nb_opt_cuts"] == int(g[q + "_nb_opt_cuts"])
+
+
+def test_sel_size_edge_cases(oracle, golden_boxqp):
+    g, tag = golden_boxqp, "spar040_030_1_d5"
+    n = int(g[tag + "_nb_vars"])
+    L = n * (n + 1) // 2
+    agg = agg_from_arrays(oracle, g[tag + "_set_inds"], g[tag + "_k"], n, g[tag + "_Q_arr"])
+    vv = g[tag + "_rnd_vars"]
+    res0 = oracle.sel_eigcut_by_ordering_on_measure(agg, L, 4, vv, sel_size=0)
+    assert isinstance(res0, list) and len(res0) == len(agg)      # reference falls through (:631-632)
+    s_big, rl_big = oracle.sel_eigcut_by_ordering_on_measure(agg, L, 4, vv, sel_size=10 ** 6)
+    assert len(rl_big) == len(agg) and s_big in (1, 4)
+    assert oracle.sel_eigcut_by_ordering_on_measure([], L, 1, vv) == []
