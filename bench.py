@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Benchmark of the cut-scoring hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one selection round over one batch of synthetic candidates, inputs resident in
+HBM: copy the LP point device->device, score every candidate (Jacobi lambda_min + MLP
+optimality measure), rank with the combined strategy (sel_size = 5000), merge the per-shard
+heads (N > 1: RCCL all-gather), and generate the eigen-cut rows of the selected candidates.
+Workload at every N: BASELINE.json configs[1] per GPU (n = 100 dense, 1e6 random 3-variable
+index sets, seed 7 + rank) -> weak scaling; `value` = candidates scored per second over all
+ranks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 10 ** 6
+NB_VARS = 100
+K = 3
+SEL = 5000
+FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only, BASELINE.md section 4
+BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
+FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(wl, sample):
+    """The oracle ("port": C restatement of NNs.so + batched LAPACK eigvalsh + numpy ranking),
+    1 core, on the first `sample` candidates of the same workload."""
+    from oracle import cutsel_oracle as oracle
+    si = np.ascontiguousarray(wl["set_inds"][:sample, :K])
+    vv, Q = wl["vars_values"], wl["Q_arr"]
+    L = NB_VARS * (NB_VARS + 1) // 2
+    t0 = time.perf_counter()
+    obj = oracle.opt_score_batch(K, si, NB_VARS, vv, Q)
+    lam = oracle.eigmin_batch(K, vv[L:][si], vv[:L][oracle.triu_positions(si, NB_VARS)])
+    order, _, _, _ = oracle.rank_arrays(4, obj, lam, min(SEL, sample))
+    for c in order[:min(SEL, sample)][:SEL]:
+        w, v = oracle.get_eigendecomp(K, vv[L:][si[c]], vv[:L][oracle.triu_positions(si[c], NB_VARS)], True)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="candidates/s", cores=1, kind="port",
+                sample="first %d of the %d candidates of this workload, same round (score eig+NN, combined "
+                       "ranking, %d eigh cut rows), %.1f s" % (sample, N_PER_GPU, min(SEL, sample), dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kernel", choices=["mfma", "simple"], default="mfma")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector
+
+    wl = synthetic.make_workload(nb_vars=NB_VARS, k=K, count=N_PER_GPU, seed=7 + rank)
+    if rank != 0:
+        # one LP point and one objective for the whole job (rank 0's); shards differ in index sets
+        wl0 = synthetic.make_instance(NB_VARS, seed=7)
+        wl["Q_arr"], wl["vars_values"] = wl0[0], wl0[1]
+    sc = _capi.Scorer(local_rank)
+    sc.set_option(_capi.OPT_TIMING, 1)
+    sc.set_option(_capi.OPT_KERNEL, _capi.KERNEL_MFMA if args.kernel == "mfma" else _capi.KERNEL_SIMPLE)
+    sc.set_network(K, *networks.load_network(K))
+    sc.set_instance(NB_VARS, wl["Q_arr"])
+    sc.set_candidates(wl["set_inds"], wl["ks"], global_base=rank * N_PER_GPU)
+    d_vars = torch.from_numpy(wl["vars_values"]).to(device)
+    ops = DeviceOps(sc, device)
+    sel = ShardedSelector(ops, N_PER_GPU)
+    lo, hi = rank * N_PER_GPU, (rank + 1) * N_PER_GPU
+
+    kernel_ms = []
+
+    def step():
+        sc.set_point_device(d_vars.data_ptr())
+        sc.score(_capi.EIG | _capi.NN)
+        res = sel.select(4, SEL)
+        ids = res["ids"].cpu().numpy()
+        mine = ids[(ids >= lo) & (ids < hi)] - lo
+        rows = sc.cut_rows(mine)
+        kernel_ms.append(sc.last_timing()[0])
+        return res, rows
+
+    for _ in range(args.warmup):
+        step()
+    del kernel_ms[:]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, rows = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = N_PER_GPU * world * args.steps
+        k_ms = float(np.mean(kernel_ms))
+        tflops = FLOPS_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e12
+        gbs = BYTES_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate cuts scored/sec (eig+NN)", "value": total / dt, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, "
+                                   "eig + neural_net_3D scoring, combined ranking sel_size=5000, cut rows",
+                       "candidates_per_gpu": N_PER_GPU, "nb_vars": NB_VARS, "k": K, "sel_size": SEL,
+                       "kernel": args.kernel, "strategy": 4},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "score_mfma_kernel<3,50,3>" if args.kernel == "mfma" else "score_simple_kernel<3>",
+                         "kernel_ms": k_ms, "flops_per_candidate": FLOPS_PER_CAND[K],
+                         "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                         "bytes_per_candidate": BYTES_PER_CAND[K]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, N_PER_GPU))
+        print(json.dumps(out), flush=True)
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * sdpcut.h -- C-ABI of the MI355X (gfx950) cut-scoring library  libsdpcut_hip.so
+ *
+ * Drop-in boundary for ONE hot path of rb2309/SDPCutSel-via-NN: the per-round scoring,
+ * ranking and generation of low-dimensional PSD cuts.  The reference reaches native code
+ * for this path through exactly one FFI:
+ *
+ *     ctypes.cdll.LoadLibrary('neural_nets/NNs.so')            cut_select_qp.py:297
+ *     double neural_net_{2,3,4,5}D(const double X[d(d+3)/2])   cut_select_qp.py:299-303, 579-582
+ *
+ * i.e. one scalar MLP evaluation per candidate per call, with the gather, the eigen-
+ * decomposition (numpy/LAPACK, cut_select_qp.py:788-797), the scoring arithmetic
+ * (:573-582), the ranking (:601-654) and the cut rows (:737-750) done in Python around it.
+ * This library replaces that per-candidate FFI by a batched, handle-based one that runs
+ * the whole per-round computation on the GPU.  Each entry point below names the reference
+ * lines it replaces.  Plain C types only: caller-owned contiguous host buffers unless a
+ * parameter is named d_* (device pointer).  Every function returns 0 on success or a
+ * negative SDPCUT_E* code; sdpcut_last_error() returns the message.  A handle is not
+ * re-entrant; different handles are independent (one per GPU / per thread).
+ *
+ * There is NO CPU fallback: every entry point needs a gfx950 device and fails with
+ * SDPCUT_ENODEVICE otherwise.
+ */
+#ifndef SDPCUT_H
+#define SDPCUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdpcut_ctx *sdpcut_handle;
+
+enum {
+    SDPCUT_OK = 0,
+    SDPCUT_EINVAL = -1,    /* bad argument (mirrors the reference's asserts, cut_select_qp.py:91-94) */
+    SDPCUT_ENODEVICE = -2, /* no usable gfx950 device */
+    SDPCUT_EHIP = -3,      /* HIP runtime error */
+    SDPCUT_ESTATE = -4,    /* call order violated (e.g. score before set_point) */
+    SDPCUT_ENOMEM = -5
+};
+
+/* score flags */
+enum { SDPCUT_EIG = 1, SDPCUT_NN = 2 };
+
+/* selection strategies, numbering of cut_select_algo (cut_select_qp.py:79-80) */
+enum { SDPCUT_STRAT_FEAS = 1, SDPCUT_STRAT_OPT = 2, SDPCUT_STRAT_COMB = 4 };
+/* Partial ranking for candidate sets sharded over several GPUs (SURVEY.md section 8 e): only
+ * the "strong" class of the combined scan (cut_select_qp.py:607-613: obj_improve > 0 and
+ * violated), by obj_improve.  Its merged per-shard heads give the global position at which
+ * the reference's scan stops.  n_total / counters[0] = size of the class. */
+enum { SDPCUT_PART_STRONG = 104 };
+
+/* kernel variants for sdpcut_set_option(SDPCUT_OPT_KERNEL, ...) */
+enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1 };
+enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2 };
+
+/* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
+#define SDPCUT_MAX_K 5
+/* row stride of the padded coefficient output of sdpcut_cut_rows: k + k(k+1)/2 <= 20 */
+#define SDPCUT_ROW_LD 20
+
+int sdpcut_version(void);
+const char *sdpcut_last_error(sdpcut_handle h); /* h may be NULL: error of the last failed create */
+
+/* Lifetime.  Replaces _load_neural_nets' LoadLibrary (cut_select_qp.py:284-303). */
+int sdpcut_create(int device_id, sdpcut_handle *out);
+int sdpcut_destroy(sdpcut_handle h);
+int sdpcut_set_option(sdpcut_handle h, int option, int64_t value);
+/* Run all work of this handle on an existing HIP stream (hipStream_t passed as void*);
+ * NULL restores the handle's own non-blocking stream. */
+int sdpcut_set_stream(sdpcut_handle h, void *hip_stream);
+int sdpcut_synchronize(sdpcut_handle h);
+
+/*
+ * Trained MLP for k-variable candidates (replaces the constants baked into NNs.so;
+ * neural_nets/neural_net_kD.m constants section).  n_layers counts the linear output
+ * layer; widths[l] = outputs of layer l (last = 1).  params is packed as
+ *   xoffset[d_in], gain[d_in], ymin,
+ *   for each layer: W[width][fan_in] row-major, b[width],
+ *   y_ymin, y_gain, y_xoffset                      with d_in = k(k+3)/2.
+ */
+int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widths,
+                       const double *params, int64_t n_params);
+
+/* Instance table: packed row-major upper triangle of the objective, length n(n+1)/2
+ * (self._Q_arr, cut_select_qp.py:318-321 / cut_select_qcqp.py:247-256). */
+int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr);
+
+/*
+ * Candidate index sets (self._agg_list[i][0], cut_select_qp.py:529-540).  set_inds is
+ * [N][ld] int32 with the first ks[i] entries of row i valid (2 <= ks[i] <= 5, ld >= max k);
+ * Xarr_inds, Q_slice and max_elem are re-derived on the device from Q_arr.
+ * global_base is added to every candidate index this handle reports (multi-GPU shards).
+ */
+int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, int32_t ld,
+                          const int32_t *ks, int64_t global_base);
+
+/* LP point vars_values = [X packed (L) | x (n)]  (cut_select_qp.py:137, 200, 547). */
+int sdpcut_set_point(sdpcut_handle h, const double *vars_values);
+/* same, from a device buffer (async copy on the handle's stream) */
+int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values);
+
+/*
+ * Score every candidate at the current point (replaces the per-candidate loop bodies of
+ * _sel_eigcut_by_ordering_on_measure, cut_select_qp.py:570-582 and :642-648):
+ *   SDPCUT_EIG: eigmin[i]      = lambda_min([[1, x^T],[x, X]])          (a6)
+ *   SDPCUT_NN : obj_improve[i] = (-S) * max_elem + nn([x | Q_slice]) * max_elem  (a4, a5)
+ * Results stay on the device; fetch with sdpcut_get_scores.
+ */
+int sdpcut_score(sdpcut_handle h, uint32_t flags);
+int sdpcut_get_scores(sdpcut_handle h, double *eigmin, double *obj_improve); /* either may be NULL */
+
+/*
+ * Rank (replaces the sorts / combined scan, cut_select_qp.py:601-632 and :649-654).
+ *   strat 1: violated candidates (lambda_min < -1e-15) by -lambda_min descending
+ *   strat 2: all candidates by obj_improve descending
+ *   strat 4: combined scan with BIG_M, using sel_size; *new_strat = 1 or 4 (:630-631)
+ * Ties keep ascending candidate index (Python's stable sort).  Writes the first
+ * min(max_out, length) entries: idx_out = global candidate index, score_out = ranking score.
+ * *n_total = full length of the reference's list (N, or nb_violated for strat 1).
+ * counters (may be NULL) = {nb_violated, strong_violated, violated_in_scan, nb_positive}.
+ * Requires a preceding sdpcut_score with the flags the strategy needs.
+ */
+int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out,
+                int64_t *idx_out, double *score_out, int64_t *n_total,
+                int32_t *new_strat, int64_t *counters);
+/* same, writing to device buffers (for the multi-GPU all-gather); returns counts on host */
+int sdpcut_rank_device(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out,
+                       void *d_idx_out, void *d_score_out, int64_t *n_written,
+                       int64_t *n_total, int32_t *new_strat, int64_t *counters);
+
+/* Read entries [offset, offset+count) of the ranking produced by the last sdpcut_rank /
+ * sdpcut_rank_device call (the reference hands back the whole sorted list; callers normally
+ * consume only its head, so the tail stays on the device until asked for). */
+int sdpcut_rank_fetch(sdpcut_handle h, int64_t offset, int64_t count, int64_t *idx_out,
+                      double *score_out);
+
+/*
+ * Order `count` entries by (score descending, secondary descending, id ascending) and write
+ * the first max_out: the replicated merge after the all-gather of per-shard top-k (SURVEY
+ * 8 e).  d_secondary may be NULL (two-level key).  The secondary key carries obj_improve for
+ * the combined strategy, whose second stable sort keeps first-sort order among equal new
+ * scores (cut_select_qp.py:601, :625).  All pointers are device pointers; ids are int64.
+ */
+int sdpcut_merge_topk_device(sdpcut_handle h, int64_t count, const void *d_scores,
+                             const void *d_secondary, const void *d_ids, int64_t max_out,
+                             void *d_score_out, void *d_id_out);
+
+/* eigmin / obj_improve of `count` candidates given by GLOBAL index, device to device
+ * (either output may be NULL). */
+int sdpcut_gather_scores_device(sdpcut_handle h, int64_t count, const void *d_ids,
+                                void *d_eig_out, void *d_obj_out);
+
+/*
+ * Eigen-cut rows of selected candidates (replaces the loop body of _gen_eigcuts_selected,
+ * cut_select_qp.py:737-750).  idx are LOCAL candidate indices (global - global_base).
+ *   lam_min[c]                 smallest eigenvalue
+ *   coef[c*SDPCUT_ROW_LD + .]  [2v0v1..2v0vk | v1^2, 2v1v2, .., vk^2] with |v_i|<=1e-15 zeroed
+ *   rhs[c]                     -v0^2
+ *   cols[c*SDPCUT_ROW_LD + .]  [L + i for i in set_inds] + Xarr_inds   (int64)
+ *   ks[c]                      candidate size k (row length = k + k(k+1)/2)
+ * A row is only meaningful when lam_min < -1e-15 (the reference skips the others).
+ */
+int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *lam_min,
+                    double *coef, double *rhs, int64_t *cols, int32_t *ks);
+
+/*
+ * Batched twin of _get_eigendecomp (cut_select_qp.py:788-797) for explicit sub-matrices:
+ * x_rho [count][k], X_rho [count][k(k+1)/2] (upper triangle, row-major).  Writes ascending
+ * eigenvalues [count][k+1] and, if evecs != NULL, eigenvectors [count][k+1][k+1] with
+ * evecs[c][i][j] = component i of eigenvector j (numpy's column convention).
+ */
+int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho,
+                     const double *X_rho, double *eigvals, double *evecs);
+
+/* Batched raw MLP forward: inputs [count][d_in] -> out [count] (the NNs.so call, batched). */
+int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs, double *out);
+
+/* Timing of the last sdpcut_score / sdpcut_rank (HIP events on the handle's stream; needs
+ * SDPCUT_OPT_TIMING = 1).  ms[0] = score kernels, ms[1] = rank. */
+int sdpcut_last_timing(sdpcut_handle h, double *ms, int n);
+
+/* Self-test hook: multiplies A[16x4] * B[4x16] with v_mfma_f64_16x16x4_f64 using the
+ * fragment maps the MLP kernel assumes; C row-major [16][16]. */
+int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDPCUT_H */

@@ -1,0 +1,263 @@
+"""ctypes binding of libsdpcut_hip.so (C-ABI declared in include/sdpcut.h).
+
+This is the only place where the host code touches native code, mirroring how the
+reference reaches NNs.so through ctypes (cut_select_qp.py:284-303).  There is no CPU
+fallback: a missing library or a missing gfx950 device raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsdpcut_hip.so")
+
+EIG, NN = 1, 2
+STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
+PART_STRONG = 104
+KERNEL_MFMA, KERNEL_SIMPLE = 0, 1
+OPT_KERNEL, OPT_TIMING = 1, 2
+ROW_LD = 20
+
+_c = ctypes
+_i32p = _c.POINTER(_c.c_int32)
+_i64p = _c.POINTER(_c.c_int64)
+_dp = _c.POINTER(_c.c_double)
+_vp = _c.c_void_p
+
+# name -> argtypes (restype is c_int unless listed in _RESTYPES); kept in one table so that the
+# CPU test-suite can check that the library exports every symbol the header declares
+SIGNATURES = {
+    "sdpcut_version": [],
+    "sdpcut_last_error": [_vp],
+    "sdpcut_create": [_c.c_int, _c.POINTER(_vp)],
+    "sdpcut_destroy": [_vp],
+    "sdpcut_set_option": [_vp, _c.c_int, _c.c_int64],
+    "sdpcut_set_stream": [_vp, _vp],
+    "sdpcut_synchronize": [_vp],
+    "sdpcut_set_network": [_vp, _c.c_int, _c.c_int, _i32p, _dp, _c.c_int64],
+    "sdpcut_set_instance": [_vp, _c.c_int32, _dp],
+    "sdpcut_set_candidates": [_vp, _c.c_int64, _i32p, _c.c_int32, _i32p, _c.c_int64],
+    "sdpcut_set_point": [_vp, _dp],
+    "sdpcut_set_point_device": [_vp, _vp],
+    "sdpcut_score": [_vp, _c.c_uint32],
+    "sdpcut_get_scores": [_vp, _dp, _dp],
+    "sdpcut_rank": [_vp, _c.c_int, _c.c_int64, _c.c_int64, _i64p, _dp, _i64p, _i32p, _i64p],
+    "sdpcut_rank_device": [_vp, _c.c_int, _c.c_int64, _c.c_int64, _vp, _vp, _i64p, _i64p, _i32p, _i64p],
+    "sdpcut_rank_fetch": [_vp, _c.c_int64, _c.c_int64, _i64p, _dp],
+    "sdpcut_merge_topk_device": [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _vp, _vp],
+    "sdpcut_gather_scores_device": [_vp, _c.c_int64, _vp, _vp, _vp],
+    "sdpcut_cut_rows": [_vp, _c.c_int64, _i64p, _dp, _dp, _dp, _i64p, _i32p],
+    "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
+    "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
+    "sdpcut_last_timing": [_vp, _dp, _c.c_int],
+    "sdpcut_mfma_probe": [_vp, _dp, _dp, _dp],
+}
+_RESTYPES = {"sdpcut_last_error": _c.c_char_p}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s not found: build it with `python -m sdpcutsel_via_nn_amd.build` "
+            "(there is no CPU fallback for the cut-scoring path)" % path)
+    lib = ctypes.CDLL(path)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, _c.c_int)
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+class SdpCutError(RuntimeError):
+    pass
+
+
+class Scorer(object):
+    """One handle of the C-ABI = one GPU.  Thin: argument marshalling and error mapping only
+    (status codes -> ValueError / RuntimeError, SURVEY.md section 8 b)."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        self._h = _vp()
+        rc = self._lib.sdpcut_create(int(device_id), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.sdpcut_last_error(None).decode()
+            self._h = None
+            raise SdpCutError("sdpcut_create failed (%d): %s" % (rc, msg))
+        self.N = 0
+        self.nb_vars = 0
+        self.base = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc == 0:
+            return
+        msg = self._lib.sdpcut_last_error(self._h).decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise SdpCutError("sdpcut error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdpcut_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        self._check(self._lib.sdpcut_set_option(self._h, option, int(value)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.sdpcut_set_stream(self._h, _vp(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        self._check(self._lib.sdpcut_synchronize(self._h))
+
+    # ------------------------------------------------------------------ setup
+    def set_network(self, k, widths, params):
+        widths = np.ascontiguousarray(widths, dtype=np.int32)
+        params = _f64(params)
+        self._check(self._lib.sdpcut_set_network(self._h, int(k), widths.shape[0], _ptr(widths, _i32p),
+                                                 _ptr(params, _dp), params.shape[0]))
+
+    def set_instance(self, nb_vars, Q_arr):
+        Q_arr = _f64(Q_arr)
+        if Q_arr.shape != (nb_vars * (nb_vars + 1) // 2,):
+            raise ValueError("Q_arr must hold the packed upper triangle, n(n+1)/2 entries")
+        self._check(self._lib.sdpcut_set_instance(self._h, int(nb_vars), _ptr(Q_arr, _dp)))
+        self.nb_vars = int(nb_vars)
+
+    def set_candidates(self, set_inds, ks, global_base=0):
+        set_inds = np.ascontiguousarray(set_inds, dtype=np.int32)
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        if set_inds.ndim != 2 or ks.shape != (set_inds.shape[0],):
+            raise ValueError("set_inds must be [N, ld] and ks [N]")
+        self._check(self._lib.sdpcut_set_candidates(self._h, set_inds.shape[0], _ptr(set_inds, _i32p),
+                                                    set_inds.shape[1], _ptr(ks, _i32p), int(global_base)))
+        self.N = int(set_inds.shape[0])
+        self.base = int(global_base)
+
+    def set_point(self, vars_values):
+        vv = _f64(vars_values)
+        n = self.nb_vars
+        if vv.shape != (n * (n + 1) // 2 + n,):
+            raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
+        self._check(self._lib.sdpcut_set_point(self._h, _ptr(vv, _dp)))
+
+    def set_point_device(self, dev_ptr):
+        self._check(self._lib.sdpcut_set_point_device(self._h, _vp(dev_ptr)))
+
+    # ------------------------------------------------------------------ hot path
+    def score(self, flags):
+        self._check(self._lib.sdpcut_score(self._h, int(flags)))
+
+    def get_scores(self, eig=True, obj=True):
+        e = np.empty(self.N) if eig else None
+        o = np.empty(self.N) if obj else None
+        self._check(self._lib.sdpcut_get_scores(self._h, _ptr(e, _dp), _ptr(o, _dp)))
+        return e, o
+
+    def rank(self, strat, sel_size=0, max_out=None):
+        """-> (idx int64[w], score float64[w], n_total, new_strat, counters dict)"""
+        cap = self.N if max_out is None else max(0, min(int(max_out), self.N))
+        idx = np.empty(max(cap, 1), dtype=np.int64)
+        sc = np.empty(max(cap, 1), dtype=np.float64)
+        n_total = _c.c_int64(0)
+        new_strat = _c.c_int32(0)
+        cnt = np.zeros(4, dtype=np.int64)
+        self._check(self._lib.sdpcut_rank(self._h, int(strat), int(sel_size), cap, _ptr(idx, _i64p), _ptr(sc, _dp),
+                                          ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+        w = min(cap, n_total.value)
+        counters = dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]), nb_positive=int(cnt[3]))
+        return idx[:w], sc[:w], int(n_total.value), int(new_strat.value), counters
+
+    def rank_fetch(self, offset, count):
+        idx = np.empty(max(count, 1), dtype=np.int64)
+        sc = np.empty(max(count, 1), dtype=np.float64)
+        self._check(self._lib.sdpcut_rank_fetch(self._h, int(offset), int(count), _ptr(idx, _i64p), _ptr(sc, _dp)))
+        return idx[:count], sc[:count]
+
+    def rank_device(self, strat, sel_size, max_out, d_idx_ptr, d_score_ptr):
+        n_written, n_total, new_strat = _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
+        cnt = np.zeros(4, dtype=np.int64)
+        self._check(self._lib.sdpcut_rank_device(self._h, int(strat), int(sel_size), int(max_out), _vp(d_idx_ptr),
+                                                 _vp(d_score_ptr), ctypes.byref(n_written), ctypes.byref(n_total),
+                                                 ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+        counters = dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]), nb_positive=int(cnt[3]))
+        return int(n_written.value), int(n_total.value), int(new_strat.value), counters
+
+    def merge_topk_device(self, count, d_scores_ptr, d_ids_ptr, max_out, d_score_out_ptr, d_id_out_ptr,
+                          d_secondary_ptr=None):
+        self._check(self._lib.sdpcut_merge_topk_device(
+            self._h, int(count), _vp(d_scores_ptr), _vp(d_secondary_ptr) if d_secondary_ptr else None,
+            _vp(d_ids_ptr), int(max_out), _vp(d_score_out_ptr), _vp(d_id_out_ptr)))
+
+    def gather_scores_device(self, count, d_ids_ptr, d_eig_out_ptr=None, d_obj_out_ptr=None):
+        self._check(self._lib.sdpcut_gather_scores_device(
+            self._h, int(count), _vp(d_ids_ptr), _vp(d_eig_out_ptr) if d_eig_out_ptr else None,
+            _vp(d_obj_out_ptr) if d_obj_out_ptr else None))
+
+    def cut_rows(self, local_idx):
+        idx = np.ascontiguousarray(local_idx, dtype=np.int64)
+        c = idx.shape[0]
+        lam = np.empty(c)
+        coef = np.empty((c, ROW_LD))
+        rhs = np.empty(c)
+        cols = np.empty((c, ROW_LD), dtype=np.int64)
+        ks = np.empty(c, dtype=np.int32)
+        self._check(self._lib.sdpcut_cut_rows(self._h, c, _ptr(idx, _i64p), _ptr(lam, _dp), _ptr(coef, _dp),
+                                              _ptr(rhs, _dp), _ptr(cols, _i64p), _ptr(ks, _i32p)))
+        return lam, coef, rhs, cols, ks
+
+    def eig_batch(self, k, x_rho, X_rho, want_vectors=False):
+        x_rho, X_rho = _f64(x_rho), _f64(X_rho)
+        c = x_rho.shape[0]
+        if x_rho.shape != (c, k) or X_rho.shape != (c, k * (k + 1) // 2):
+            raise ValueError("x_rho must be [count, k] and X_rho [count, k(k+1)/2]")
+        w = np.empty((c, k + 1))
+        v = np.empty((c, k + 1, k + 1)) if want_vectors else None
+        self._check(self._lib.sdpcut_eig_batch(self._h, int(k), c, _ptr(x_rho, _dp), _ptr(X_rho, _dp), _ptr(w, _dp),
+                                               _ptr(v, _dp)))
+        return (w, v) if want_vectors else w
+
+    def nn_batch(self, k, inputs):
+        inputs = _f64(inputs)
+        c = inputs.shape[0]
+        if inputs.shape != (c, k * (k + 3) // 2):
+            raise ValueError("inputs must be [count, k(k+3)/2]")
+        out = np.empty(c)
+        self._check(self._lib.sdpcut_nn_batch(self._h, int(k), c, _ptr(inputs, _dp), _ptr(out, _dp)))
+        return out
+
+    def last_timing(self):
+        ms = np.zeros(2)
+        self._check(self._lib.sdpcut_last_timing(self._h, _ptr(ms, _dp), 2))
+        return float(ms[0]), float(ms[1])
+
+    def mfma_probe(self, A, B):
+        A, B = _f64(A), _f64(B)
+        assert A.shape == (16, 4) and B.shape == (4, 16)
+        C = np.empty((16, 16))
+        self._check(self._lib.sdpcut_mfma_probe(self._h, _ptr(A, _dp), _ptr(B, _dp), _ptr(C, _dp)))
+        return C

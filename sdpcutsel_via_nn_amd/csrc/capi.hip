@@ -1,0 +1,567 @@
+// extern "C" surface of libsdpcut_hip.so (declared in include/sdpcut.h).
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+static std::string g_create_err;
+static std::mutex g_mu;
+
+int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    else {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_create_err = msg;
+    }
+    return code;
+}
+
+extern "C" {
+
+int sdpcut_version(void) { return 100; }
+
+const char *sdpcut_last_error(sdpcut_handle h)
+{
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_create_err.c_str();
+}
+
+int sdpcut_create(int device_id, sdpcut_handle *out)
+{
+    if (!out) return sdpcut_fail(nullptr, SDPCUT_EINVAL, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return sdpcut_fail(nullptr, SDPCUT_ENODEVICE,
+                           "no HIP device visible: this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return sdpcut_fail(nullptr, SDPCUT_EINVAL, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+        return sdpcut_fail(nullptr, SDPCUT_EHIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return sdpcut_fail(nullptr, SDPCUT_ENODEVICE,
+                           std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    sdpcut_ctx *h = new (std::nothrow) sdpcut_ctx();
+    if (!h) return sdpcut_fail(nullptr, SDPCUT_ENOMEM, "out of host memory");
+    h->device = device_id;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&h->d_counters, 8 * sizeof(int64_t)) != hipSuccess) {
+        delete h;
+        return sdpcut_fail(nullptr, SDPCUT_EHIP, "stream / counter allocation failed");
+    }
+    h->stream = h->own_stream;
+    for (int i = 0; i < 4; ++i) hipEventCreate(&h->ev[i]);
+    *out = h;
+    return SDPCUT_OK;
+}
+
+static void free_candidates(sdpcut_ctx *h)
+{
+    for (int k = 0; k <= SDPCUT_MAX_K; ++k) {
+        hipFree(h->bucket[k].d_set);
+        hipFree(h->bucket[k].d_orig);
+        h->bucket[k] = Bucket();
+    }
+    hipFree(h->d_set_orig); hipFree(h->d_k); hipFree(h->d_eig); hipFree(h->d_obj);
+    h->d_set_orig = nullptr; h->d_k = nullptr; h->d_eig = nullptr; h->d_obj = nullptr;
+    h->N = 0; h->scored = 0; h->last_total = -1;
+}
+
+int sdpcut_destroy(sdpcut_handle h)
+{
+    if (!h) return SDPCUT_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_candidates(h);
+    free_rank_ws(h);
+    for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
+    hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
+    for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
+{
+    if (!h) return SDPCUT_EINVAL;
+    switch (option) {
+    case SDPCUT_OPT_KERNEL:
+        if (value != SDPCUT_KERNEL_MFMA && value != SDPCUT_KERNEL_SIMPLE)
+            return sdpcut_fail(h, SDPCUT_EINVAL, "unknown kernel variant");
+        h->kernel_variant = (int)value;
+        return SDPCUT_OK;
+    case SDPCUT_OPT_TIMING:
+        h->timing = value != 0;
+        return SDPCUT_OK;
+    }
+    return sdpcut_fail(h, SDPCUT_EINVAL, "unknown option");
+}
+
+int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
+{
+    if (!h) return SDPCUT_EINVAL;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return SDPCUT_OK;
+}
+
+int sdpcut_synchronize(sdpcut_handle h)
+{
+    if (!h) return SDPCUT_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widths, const double *params,
+                       int64_t n_params)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
+    if (n_layers < 2 || n_layers > MAX_LAYERS || !widths || !params)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad layer description");
+    const int d_in = k * (k + 3) / 2;
+    const int nh = n_layers - 1;
+    const int H = widths[0];
+    if (widths[n_layers - 1] != 1) return sdpcut_fail(h, SDPCUT_EINVAL, "last layer must have one output");
+    for (int l = 0; l < nh; ++l)
+        if (widths[l] != H || H < 1 || H > MAX_HIDDEN)
+            return sdpcut_fail(h, SDPCUT_EINVAL, "hidden layers must share one width <= 64");
+    int64_t need = 2 * d_in + 1 + 3;
+    {
+        int fan = d_in;
+        for (int l = 0; l < n_layers; ++l) { need += (int64_t)widths[l] * fan + widths[l]; fan = widths[l]; }
+    }
+    if (need != n_params) return sdpcut_fail(h, SDPCUT_EINVAL, "n_params does not match the layer description");
+    HIP_TRY(h, hipSetDevice(h->device));
+
+    // ---- unpack
+    const double *p = params;
+    const double *xoffset = p; p += d_in;
+    const double *gain = p; p += d_in;
+    const double ymin = *p++;
+    const double *W[MAX_LAYERS], *B[MAX_LAYERS];
+    {
+        int fan = d_in;
+        for (int l = 0; l < n_layers; ++l) {
+            W[l] = p; p += (int64_t)widths[l] * fan;
+            B[l] = p; p += widths[l];
+            fan = widths[l];
+        }
+    }
+    const double y_ymin = p[0], y_gain = p[1], y_xoffset = p[2];
+
+    // ---- pack the device blob: inmap | bias | wout | raw W,b | A-fragments
+    const int T = 4;
+    const int s0 = (d_in + 3) / 4, sh = (H + 3) / 4;
+    std::vector<double> blob;
+    auto reserve = [&](size_t n) { size_t o = blob.size(); blob.resize(o + n, 0.0); return o; };
+    const size_t o_inmap = reserve(2 * d_in);
+    for (int i = 0; i < d_in; ++i) { blob[o_inmap + i] = xoffset[i]; blob[o_inmap + d_in + i] = gain[i]; }
+    const size_t o_bias = reserve((size_t)nh * 64);
+    for (int l = 0; l < nh; ++l)
+        for (int j = 0; j < H; ++j) blob[o_bias + l * 64 + j] = B[l][j];
+    const size_t o_wout = reserve(64);
+    for (int j = 0; j < H; ++j) blob[o_wout + j] = W[nh][j];
+    size_t o_rw[MAX_LAYERS], o_rb[MAX_LAYERS];
+    {
+        int fan = d_in;
+        for (int l = 0; l < n_layers; ++l) {
+            o_rw[l] = reserve((size_t)widths[l] * fan);
+            std::memcpy(&blob[o_rw[l]], W[l], sizeof(double) * widths[l] * fan);
+            o_rb[l] = reserve(widths[l]);
+            std::memcpy(&blob[o_rb[l]], B[l], sizeof(double) * widths[l]);
+            fan = widths[l];
+        }
+    }
+    // A-fragment of v_mfma_f64_16x16x4_f64: lane l holds A[row = l & 15][k = l >> 4]
+    // => frag[t][s][l] = W[16 t + (l & 15)][4 s + (l >> 4)], zero outside the matrix
+    const size_t o_frag = reserve((size_t)T * (s0 + (size_t)(nh - 1) * sh) * 64);
+    {
+        size_t o = o_frag;
+        int fan = d_in;
+        for (int l = 0; l < nh; ++l) {
+            const int S = (l == 0) ? s0 : sh;
+            for (int t = 0; t < T; ++t)
+                for (int s = 0; s < S; ++s)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int row = 16 * t + (ln & 15), col = 4 * s + (ln >> 4);
+                        blob[o++] = (row < H && col < fan) ? W[l][(size_t)row * fan + col] : 0.0;
+                    }
+            fan = H;
+        }
+    }
+    NetHost &nh_ = h->net[k];
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(nh_.d_blob);
+    nh_.d_blob = nullptr;
+    nh_.set = false;
+    HIP_TRY(h, hipMalloc((void **)&nh_.d_blob, blob.size() * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(nh_.d_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+    NetDev &d = nh_.dev;
+    d = NetDev{};
+    d.d_in = d_in; d.n_hidden = nh; d.width = H; d.s0 = s0; d.sh = sh;
+    d.inmap = nh_.d_blob + o_inmap;
+    d.bias = nh_.d_blob + o_bias;
+    d.wout = nh_.d_blob + o_wout;
+    d.wfrag = nh_.d_blob + o_frag;
+    for (int l = 0; l < n_layers; ++l) { d.raw_w[l] = nh_.d_blob + o_rw[l]; d.raw_b[l] = nh_.d_blob + o_rb[l]; }
+    d.ymin = ymin; d.b_out = B[nh][0]; d.y_ymin = y_ymin; d.y_gain = y_gain; d.y_xoffset = y_xoffset;
+    nh_.set = true;
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (nb_vars < 2 || nb_vars > 40000 || !Q_arr) return sdpcut_fail(h, SDPCUT_EINVAL, "bad instance");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int64_t L = (int64_t)nb_vars * (nb_vars + 1) / 2;
+    hipFree(h->d_Q); hipFree(h->d_vars);
+    h->d_Q = nullptr; h->d_vars = nullptr; h->have_point = false; h->scored = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->d_Q, L * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_vars, (L + nb_vars) * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->d_Q, Q_arr, L * sizeof(double), hipMemcpyHostToDevice));
+    h->nb_vars = nb_vars;
+    h->L = L;
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, int32_t ld, const int32_t *ks,
+                          int64_t global_base)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
+    if (N < 0 || N > 0x7fffffffLL || (N > 0 && (!set_inds || !ks)) || ld < 2)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad candidate list");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_candidates(h);
+    h->base = global_base;
+    // validate + bucket by size on the host (once per instance)
+    int64_t cnt[SDPCUT_MAX_K + 1] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < N; ++i) {
+        const int k = ks[i];
+        if (k < 2 || k > SDPCUT_MAX_K || k > ld) return sdpcut_fail(h, SDPCUT_EINVAL, "candidate size must be 2..5");
+        for (int a = 0; a < k; ++a) {
+            const int32_t v = set_inds[i * ld + a];
+            if (v < 0 || v >= h->nb_vars) return sdpcut_fail(h, SDPCUT_EINVAL, "variable index out of range");
+        }
+        ++cnt[k];
+    }
+    std::vector<int32_t> pad((size_t)N * 5, -1), kk((size_t)N);
+    std::vector<int32_t> soa[SDPCUT_MAX_K + 1], orig[SDPCUT_MAX_K + 1];
+    int64_t fill[SDPCUT_MAX_K + 1] = {0, 0, 0, 0, 0, 0};
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k) { soa[k].resize((size_t)cnt[k] * k); orig[k].resize((size_t)cnt[k]); }
+    for (int64_t i = 0; i < N; ++i) {
+        const int k = ks[i];
+        kk[i] = k;
+        const int64_t p = fill[k]++;
+        orig[k][p] = (int32_t)i;
+        for (int a = 0; a < k; ++a) {
+            const int32_t v = set_inds[i * ld + a];
+            pad[i * 5 + a] = v;
+            soa[k][(size_t)a * cnt[k] + p] = v;
+        }
+    }
+    const size_t nn = (size_t)(N < 1 ? 1 : N);
+    HIP_TRY(h, hipMalloc((void **)&h->d_set_orig, nn * 5 * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_k, nn * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_eig, nn * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_obj, nn * sizeof(double)));
+    if (N > 0) {
+        HIP_TRY(h, hipMemcpy(h->d_set_orig, pad.data(), (size_t)N * 5 * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_k, kk.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
+        Bucket &b = h->bucket[k];
+        b.n = cnt[k];
+        if (!cnt[k]) continue;
+        HIP_TRY(h, hipMalloc((void **)&b.d_set, soa[k].size() * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&b.d_orig, orig[k].size() * sizeof(int32_t)));
+        HIP_TRY(h, hipMemcpy(b.d_set, soa[k].data(), soa[k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(b.d_orig, orig[k].data(), orig[k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    h->N = N;
+    int rc = ensure_rank_ws(h, N);
+    if (rc) return rc;
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
+    if (!vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "vars_values is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_vars, vars_values, (h->L + h->nb_vars) * sizeof(double), hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // caller may reuse its buffer immediately
+    h->have_point = true;
+    h->scored = 0;
+    h->last_total = -1;
+    return SDPCUT_OK;
+}
+
+int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
+    if (!d_vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "d_vars_values is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_vars, d_vars_values, (h->L + h->nb_vars) * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->stream));
+    h->have_point = true;
+    h->scored = 0;
+    return SDPCUT_OK;
+}
+
+int sdpcut_score(sdpcut_handle h, uint32_t flags)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!(flags & (SDPCUT_EIG | SDPCUT_NN)) || (flags & ~(uint32_t)(SDPCUT_EIG | SDPCUT_NN)))
+        return sdpcut_fail(h, SDPCUT_EINVAL, "flags must be a combination of SDPCUT_EIG and SDPCUT_NN");
+    if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
+    if (!h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    int rc = launch_score(h, flags);
+    if (rc) return rc;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    h->scored |= flags;
+    return SDPCUT_OK;
+}
+
+int sdpcut_get_scores(sdpcut_handle h, double *eigmin, double *obj_improve)
+{
+    if (!h) return SDPCUT_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (eigmin) {
+        if (!(h->scored & SDPCUT_EIG)) return sdpcut_fail(h, SDPCUT_ESTATE, "eigenvalues not scored");
+        HIP_TRY(h, hipMemcpyAsync(eigmin, h->d_eig, h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (obj_improve) {
+        if (!(h->scored & SDPCUT_NN)) return sdpcut_fail(h, SDPCUT_ESTATE, "optimality measure not scored");
+        HIP_TRY(h, hipMemcpyAsync(obj_improve, h->d_obj, h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+static int ensure_stage(sdpcut_ctx *h, size_t bytes)
+{
+    if (bytes <= h->stage_bytes) return 0;
+    hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->d_stage, bytes));
+    h->stage_bytes = bytes;
+    return 0;
+}
+
+static int check_rank_args(sdpcut_ctx *h, int strat)
+{
+    const bool part = strat == SDPCUT_PART_STRONG;
+    if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_STRAT_COMB && !part)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "strategy must be 1 (feasibility), 2 (optimality) or 4 (combined)");
+    const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
+                          : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
+    if ((h->scored & need) != need) return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
+    return 0;
+}
+
+int sdpcut_rank_device(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, void *d_idx_out,
+                       void *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
+                       int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    int rc = check_rank_args(h, strat);
+    if (rc) return rc;
+    if (max_out < 0 || (max_out > 0 && (!d_idx_out || !d_score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    rc = rank_on_device(h, strat, sel_size, max_out, (int64_t *)d_idx_out, (double *)d_score_out, n_written, n_total,
+                        new_strat, counters);
+    if (rc) return rc;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, int64_t *idx_out, double *score_out,
+                int64_t *n_total, int32_t *new_strat, int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (max_out < 0 || (max_out > 0 && (!idx_out || !score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int64_t cap = max_out < h->N ? max_out : h->N;
+    int rc = ensure_stage(h, (size_t)(cap < 1 ? 1 : cap) * 16);
+    if (rc) return rc;
+    int64_t *d_idx = (int64_t *)h->d_stage;
+    double *d_sc = (double *)((char *)h->d_stage + (size_t)(cap < 1 ? 1 : cap) * 8);
+    int64_t w = 0;
+    rc = sdpcut_rank_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters);
+    if (rc) return rc;
+    if (w > 0) {
+        HIP_TRY(h, hipMemcpyAsync(idx_out, d_idx, w * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(score_out, d_sc, w * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_rank_fetch(sdpcut_handle h, int64_t offset, int64_t count, int64_t *idx_out, double *score_out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (h->last_total < 0) return sdpcut_fail(h, SDPCUT_ESTATE, "no ranking available: call sdpcut_rank first");
+    if (offset < 0 || count < 0 || offset + count > h->last_total || (count > 0 && (!idx_out || !score_out)))
+        return sdpcut_fail(h, SDPCUT_EINVAL, "window outside the last ranking");
+    if (count == 0) return SDPCUT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_stage(h, (size_t)count * 16);
+    if (rc) return rc;
+    int64_t *d_idx = (int64_t *)h->d_stage;
+    double *d_sc = (double *)((char *)h->d_stage + (size_t)count * 8);
+    rc = rank_fetch_on_device(h, offset, count, d_idx, d_sc);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(idx_out, d_idx, count * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(score_out, d_sc, count * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_merge_topk_device(sdpcut_handle h, int64_t count, const void *d_scores, const void *d_secondary,
+                             const void *d_ids, int64_t max_out, void *d_score_out, void *d_id_out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (count < 0 || max_out < 0 || (count > 0 && max_out > 0 && (!d_scores || !d_ids || !d_score_out || !d_id_out)))
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad merge arguments");
+    if (count > 0x7fffffffLL) return sdpcut_fail(h, SDPCUT_EINVAL, "merge too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return merge_topk_on_device(h, count, (const double *)d_scores, (const double *)d_secondary,
+                                (const int64_t *)d_ids, max_out, (double *)d_score_out, (int64_t *)d_id_out);
+}
+
+int sdpcut_gather_scores_device(sdpcut_handle h, int64_t count, const void *d_ids, void *d_eig_out, void *d_obj_out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (count < 0 || (count > 0 && !d_ids)) return sdpcut_fail(h, SDPCUT_EINVAL, "bad gather arguments");
+    if ((d_eig_out && !(h->scored & SDPCUT_EIG)) || (d_obj_out && !(h->scored & SDPCUT_NN)))
+        return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return gather_scores_on_device(h, count, (const int64_t *)d_ids, (double *)d_eig_out, (double *)d_obj_out);
+}
+
+int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *lam_min, double *coef, double *rhs,
+                    int64_t *cols, int32_t *ks)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!h->have_point || !h->d_set_orig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
+    if (count < 0 || (count > 0 && (!idx || !lam_min || !coef || !rhs || !cols || !ks)))
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad cut_rows arguments");
+    if (count == 0) return SDPCUT_OK;
+    for (int64_t i = 0; i < count; ++i)
+        if (idx[i] < 0 || idx[i] >= h->N) return sdpcut_fail(h, SDPCUT_EINVAL, "candidate index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // staging layout: idx | lam | rhs | coef | cols | ks
+    const size_t c = (size_t)count;
+    const size_t bytes = c * 8 * (3 + 2 * SDPCUT_ROW_LD) + c * 4;
+    int rc = ensure_stage(h, bytes);
+    if (rc) return rc;
+    char *p = (char *)h->d_stage;
+    int64_t *d_idx = (int64_t *)p; p += c * 8;
+    double *d_lam = (double *)p; p += c * 8;
+    double *d_rhs = (double *)p; p += c * 8;
+    double *d_coef = (double *)p; p += c * 8 * SDPCUT_ROW_LD;
+    int64_t *d_cols = (int64_t *)p; p += c * 8 * SDPCUT_ROW_LD;
+    int32_t *d_ks = (int32_t *)p;
+    HIP_TRY(h, hipMemcpyAsync(d_idx, idx, c * 8, hipMemcpyHostToDevice, h->stream));
+    rc = launch_cut_rows(h, count, d_idx, d_lam, d_coef, d_rhs, d_cols, d_ks);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(lam_min, d_lam, c * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(rhs, d_rhs, c * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(coef, d_coef, c * 8 * SDPCUT_ROW_LD, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(cols, d_cols, c * 8 * SDPCUT_ROW_LD, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(ks, d_ks, c * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho, const double *X_rho,
+                     double *eigvals, double *evecs)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
+    if (count < 0 || (count > 0 && (!x_rho || !X_rho || !eigvals))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad eig_batch arguments");
+    if (count == 0) return SDPCUT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t c = (size_t)count, m = (size_t)k * (k + 1) / 2, D = (size_t)k + 1;
+    const size_t bytes = c * 8 * (k + m + D + D * D);
+    int rc = ensure_stage(h, bytes);
+    if (rc) return rc;
+    double *d_x = (double *)h->d_stage, *d_X = d_x + c * k, *d_w = d_X + c * m, *d_v = d_w + c * D;
+    HIP_TRY(h, hipMemcpyAsync(d_x, x_rho, c * k * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_X, X_rho, c * m * 8, hipMemcpyHostToDevice, h->stream));
+    rc = launch_eig_batch(h, k, count, d_x, d_X, d_w, evecs ? d_v : nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(eigvals, d_w, c * D * 8, hipMemcpyDeviceToHost, h->stream));
+    if (evecs) HIP_TRY(h, hipMemcpyAsync(evecs, d_v, c * D * D * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs, double *out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
+    if (!h->net[k].set) return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
+    if (count < 0 || (count > 0 && (!inputs || !out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad nn_batch arguments");
+    if (count == 0) return SDPCUT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t c = (size_t)count, d = (size_t)k * (k + 3) / 2;
+    int rc = ensure_stage(h, c * 8 * (d + 1));
+    if (rc) return rc;
+    double *d_in = (double *)h->d_stage, *d_out = d_in + c * d;
+    HIP_TRY(h, hipMemcpyAsync(d_in, inputs, c * d * 8, hipMemcpyHostToDevice, h->stream));
+    rc = launch_nn_batch(h, k, count, d_in, d_out);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, d_out, c * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_last_timing(sdpcut_handle h, double *ms, int n)
+{
+    if (!h || !ms || n < 1) return SDPCUT_EINVAL;
+    if (!h->timing) return sdpcut_fail(h, SDPCUT_ESTATE, "enable SDPCUT_OPT_TIMING first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess) a = -1.f;
+    if (hipEventElapsedTime(&b, h->ev[2], h->ev[3]) != hipSuccess) b = -1.f;
+    ms[0] = a;
+    if (n > 1) ms[1] = b;
+    return SDPCUT_OK;
+}
+
+int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C)
+{
+    if (!h || !A || !B || !C) return SDPCUT_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_stage(h, 8 * (64 + 64 + 256));
+    if (rc) return rc;
+    double *dA = (double *)h->d_stage, *dB = dA + 64, *dC = dB + 64;
+    HIP_TRY(h, hipMemcpyAsync(dA, A, 64 * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dB, B, 64 * 8, hipMemcpyHostToDevice, h->stream));
+    rc = launch_mfma_probe(h, dA, dB, dC);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(C, dC, 256 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,110 @@
+// Shared host-side declarations of libsdpcut_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sdpcut.h"
+
+#define SDPCUT_NEG_EIGVAL (-1e-15) /* _THRES_NEG_EIGVAL, cut_select_qp.py:24 */
+#define SDPCUT_BIG_M 1000.0        /* _BIG_M, cut_select_qp.py:26 */
+
+#define MAX_HIDDEN 64
+#define MAX_LAYERS 5
+
+// Device-side description of one trained MLP (k = 2..5); passed to kernels by value.
+struct NetDev {
+    int d_in;
+    int n_hidden;          // hidden (tansig) layers
+    int width;             // hidden width (all hidden layers equal: 64 or 50)
+    int s0, sh;            // k-steps (of 4) of the first / the other hidden layers
+    const double *wfrag;   // MFMA A-fragments: layer-major, then [t][s][lane]
+    const double *bias;    // [n_hidden][64] zero padded
+    const double *wout;    // [64] zero padded output weights
+    const double *inmap;   // xoffset[d_in] | gain[d_in]
+    const double *raw_w[MAX_LAYERS]; // row-major [out][in] (simple kernel)
+    const double *raw_b[MAX_LAYERS];
+    double ymin, b_out, y_ymin, y_gain, y_xoffset;
+};
+
+struct Bucket {
+    int64_t n = 0;
+    int32_t *d_set = nullptr;   // SoA [k][n]
+    int32_t *d_orig = nullptr;  // [n] local candidate index (position in caller's list)
+};
+
+struct NetHost {
+    bool set = false;
+    NetDev dev{};
+    double *d_blob = nullptr;   // one allocation behind all device pointers of dev
+};
+
+struct sdpcut_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int kernel_variant = SDPCUT_KERNEL_MFMA;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms_score = 0.f, ms_rank = 0.f;
+    int n_cu = 256;
+
+    int32_t nb_vars = 0;
+    int64_t L = 0;
+    double *d_Q = nullptr;      // [L]
+    double *d_vars = nullptr;   // [L + n]
+    bool have_point = false;
+
+    int64_t N = 0, base = 0;
+    Bucket bucket[SDPCUT_MAX_K + 1];
+    int32_t *d_set_orig = nullptr; // [N][5] padded, caller order
+    int32_t *d_k = nullptr;        // [N]
+    double *d_eig = nullptr, *d_obj = nullptr; // [N] caller order
+    uint32_t scored = 0;
+    int64_t last_total = -1;       // length of the last ranking (-1: none), see sdpcut_rank_fetch
+
+    NetHost net[SDPCUT_MAX_K + 1];
+
+    // ranking workspace (sized to N by ensure_rank_ws)
+    int64_t ws_n = 0;
+    uint64_t *d_key_a = nullptr, *d_key_b = nullptr;
+    uint32_t *d_val_a = nullptr, *d_val_b = nullptr;
+    int32_t *d_flag = nullptr, *d_scan = nullptr;
+    int64_t *d_counters = nullptr; // [8]
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    // small staging
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return sdpcut_fail((h), SDPCUT_EHIP,                                           \
+                               std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    } while (0)
+
+// score.hip
+int launch_score(sdpcut_ctx *h, uint32_t flags);
+int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_idx, double *d_lam, double *d_coef,
+                    double *d_rhs, int64_t *d_cols, int32_t *d_ks);
+int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
+                     double *d_vals, double *d_vecs);
+int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);
+int launch_mfma_probe(sdpcut_ctx *h, const double *d_A, const double *d_B, double *d_C);
+
+// rank.hip
+int ensure_rank_ws(sdpcut_ctx *h, int64_t n);
+int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
+                   double *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
+                   int64_t *counters);
+int merge_topk_on_device(sdpcut_ctx *h, int64_t count, const double *d_scores, const double *d_secondary,
+                         const int64_t *d_ids, int64_t max_out, double *d_score_out, int64_t *d_id_out);
+int gather_scores_on_device(sdpcut_ctx *h, int64_t count, const int64_t *d_ids, double *d_eig_out, double *d_obj_out);
+int rank_fetch_on_device(sdpcut_ctx *h, int64_t offset, int64_t count, int64_t *d_idx_out, double *d_score_out);
+void free_rank_ws(sdpcut_ctx *h);

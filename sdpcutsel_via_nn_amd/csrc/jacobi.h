@@ -1,0 +1,125 @@
+// Cyclic Jacobi eigen-solver for the (k+1)x(k+1) lifted matrices, one matrix per lane,
+// everything in registers (all loops over matrix indices are fully unrolled so that every
+// array index is a compile-time constant -- runtime-indexed arrays would go to scratch).
+//
+// Replaces numpy.linalg.eigvalsh / eigh (LAPACK dsyevd) at cut_select_qp.py:796-797 for
+// D = 3..6.  Jacobi is used because for these tiny symmetric matrices it is branch-light,
+// needs no pivoting and delivers eigenvalues to a few ulp of ||A|| (a00 = 1, entries in
+// [0,1]), i.e. the same accuracy class as LAPACK.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define JACOBI_MAX_SWEEPS 24
+
+// One rotation annihilating a[P][Q].  t = tan(phi) from the numerically stable form
+// t = 2apq / (d + sign(d) sqrt(d^2 + 4apq^2)),  d = aqq - app.
+template <int D, int P, int Q, bool VEC>
+__device__ __forceinline__ void jacobi_rotate(double (&a)[D][D], double (&v)[D][D])
+{
+    const double apq = a[P][Q];
+    // |apq| <= 1e-140 is numerically zero against a00 = 1 and would let d^2 + 4apq^2 underflow
+    if (fabs(apq) > 1e-140) {
+        const double d = a[Q][Q] - a[P][P];
+        const double b = 2.0 * apq;
+        const double r = sqrt(fma(d, d, b * b));
+        const double t = b / (d + copysign(r, d));
+        const double c = rsqrt(fma(t, t, 1.0));
+        const double s = t * c;
+        a[P][P] = fma(-t, apq, a[P][P]);
+        a[Q][Q] = fma(t, apq, a[Q][Q]);
+        a[P][Q] = 0.0;
+        a[Q][P] = 0.0;
+#pragma unroll
+        for (int r_ = 0; r_ < D; ++r_) {
+            if (r_ != P && r_ != Q) {
+                const double arp = a[r_][P], arq = a[r_][Q];
+                const double np_ = fma(c, arp, -s * arq);
+                const double nq_ = fma(s, arp, c * arq);
+                a[r_][P] = np_; a[P][r_] = np_;
+                a[r_][Q] = nq_; a[Q][r_] = nq_;
+            }
+        }
+        if (VEC) {
+#pragma unroll
+            for (int r_ = 0; r_ < D; ++r_) {
+                const double vrp = v[r_][P], vrq = v[r_][Q];
+                v[r_][P] = fma(c, vrp, -s * vrq);
+                v[r_][Q] = fma(s, vrp, c * vrq);
+            }
+        }
+    }
+}
+
+template <int D, int P, int Q, bool VEC>
+struct JacobiSweep {
+    __device__ __forceinline__ static void run(double (&a)[D][D], double (&v)[D][D])
+    {
+        jacobi_rotate<D, P, Q, VEC>(a, v);
+        if constexpr (Q + 1 < D)
+            JacobiSweep<D, P, Q + 1, VEC>::run(a, v);
+        else if constexpr (P + 2 < D)
+            JacobiSweep<D, P + 1, P + 2, VEC>::run(a, v);
+    }
+};
+
+// Diagonalises the symmetric matrix a (full storage, both triangles filled) in place.
+// On return the diagonal of a holds the eigenvalues (unsorted) and, if VEC, the columns
+// of v the corresponding orthonormal eigenvectors.
+template <int D, bool VEC>
+__device__ __forceinline__ void jacobi_eig(double (&a)[D][D], double (&v)[D][D])
+{
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) scale += fabs(a[i][i]);
+    // off-diagonal mass below which a further sweep cannot move any eigenvalue by more than
+    // ~1e-19*scale (second-order perturbation), far below the fp64 resolution of scale
+    const double tol = scale * scale * 1e-38;
+#pragma unroll 1
+    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = p + 1; q < D; ++q) off = fma(a[p][q], a[p][q], off);
+        if (!(off > tol)) break;
+        JacobiSweep<D, 0, 1, VEC>::run(a, v);
+    }
+}
+
+// smallest diagonal entry
+template <int D>
+__device__ __forceinline__ double diag_min(const double (&a)[D][D])
+{
+    double m = a[0][0];
+#pragma unroll
+    for (int i = 1; i < D; ++i) m = fmin(m, a[i][i]);
+    return m;
+}
+
+// Fill the lifted matrix [[1, x^T],[x, X]] from x (k) and the row-major upper triangle X.
+template <int K>
+__device__ __forceinline__ void fill_lifted(double (&a)[K + 1][K + 1], const double (&x)[K],
+                                            const double (&X)[K * (K + 1) / 2])
+{
+    a[0][0] = 1.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        a[0][i + 1] = x[i];
+        a[i + 1][0] = x[i];
+    }
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = i; j < K; ++j) {
+            a[i + 1][j + 1] = X[m];
+            a[j + 1][i + 1] = X[m];
+            ++m;
+        }
+}

@@ -1,0 +1,580 @@
+// Scoring kernels of libsdpcut_hip.so -- hand-written for gfx950 (CDNA4, wave64).
+//
+// One launch per candidate size k scores every k-variable candidate at the current LP
+// point (reference: the loop bodies of _sel_eigcut_by_ordering_on_measure,
+// cut_select_qp.py:570-582 and :642-648, plus NNs.so and numpy.linalg.eigvalsh under them):
+//
+//   phase A  lane = candidate: read the index set (SoA, coalesced), gather x_rho / X_rho /
+//            Q_rho from the HBM-resident, cache-hot tables, derive max_elem / Q_slice / S,
+//            Jacobi lambda_min of the lifted matrix in registers, stage the mapminmax'ed MLP
+//            inputs in LDS (feature-major, one 64-candidate strip per wave);
+//   phase B  the MLP on the matrix cores: H^T = tansig(W * X^T + b) with
+//            v_mfma_f64_16x16x4_f64, neurons on the M axis and candidates on the N axis, so
+//            that the C/D fragment of one layer IS the B fragment of the next (row =
+//            (lane>>4) + 4*reg is exactly k-step reg of row tile t) -- activations never leave
+//            registers; weights are pre-packed host-side into A-fragment order and streamed
+//            from L2 as coalesced 512-B wave loads; tansig runs on the VALU between MFMAs.
+//
+// A second, deliberately simple kernel (lane = candidate, reference operation order, no
+// MFMA) exists for cross-checking and A/B timing (SDPCUT_KERNEL_SIMPLE).
+#include "common.h"
+#include "jacobi.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct ScoreArgs {
+    const int32_t *set;   // SoA [K][n]
+    const int32_t *orig;  // [n]
+    int64_t n;
+    const double *vars;   // [L + nv]: X packed | x
+    const double *Q;      // [L]
+    int32_t nv;
+    int64_t L;
+    double *eig_out;      // [N] caller order
+    double *obj_out;      // [N]
+    uint32_t flags;
+    NetDev net;
+};
+
+// ------------------------------------------------------------------------------------------
+// gather of one candidate (cut_select_qp.py:529-540 record + :573-575 slices)
+template <int K>
+struct Cand {
+    static constexpr int M = K * (K + 1) / 2;
+    double x[K];
+    double X[M];
+    double q[M];     // Q_slice (already divided by max_elem)
+    double max_elem;
+    double negSM;    // (-S) * max_elem
+};
+
+template <int K>
+__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set, int64_t n, int64_t c,
+                                                 const double *vars, const double *Q, int32_t nv,
+                                                 int64_t L, bool want_q)
+{
+    constexpr int M = K * (K + 1) / 2;
+    int32_t s[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) s[a] = set[(int64_t)a * n + c];
+#pragma unroll
+    for (int a = 0; a < K; ++a) cd.x[a] = vars[L + s[a]];
+    int32_t pos[M];
+    {
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            // packed row-major upper-triangle position, cut_select_qp.py:531
+            const int32_t rowbase = nv * s[a] - (s[a] * (s[a] + 1)) / 2;
+#pragma unroll
+            for (int b = a; b < K; ++b) pos[m++] = rowbase + s[b];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) cd.X[m] = vars[pos[m]];
+    if (want_q) {
+        double amax = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            cd.q[m] = Q[pos[m]];
+            amax = fmax(amax, fabs(cd.q[m]));
+        }
+        double me = (double)K * amax;       // :536  (exact: K * |integer-ish|, one rounding)
+        if (me == 0.0) me += 1.0;           // :537
+        cd.max_elem = me;
+        // reference operation order, no contraction:  S = ((0 + q0*X0) + q1*X1) + ...
+        {
+#pragma clang fp contract(off)
+            double S = 0.0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                cd.q[m] = cd.q[m] / me;     // np.divide, :538
+                S = S + cd.q[m] * cd.X[m];  // :575
+            }
+            cd.negSM = (-S) * me;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
+{
+    double a[K + 1][K + 1], v[K + 1][K + 1];
+    fill_lifted<K>(a, cd.x, cd.X);
+    jacobi_eig<K + 1, false>(a, v);
+    return diag_min<K + 1>(a);
+}
+
+// tansig as MATLAB defines it (neural_net_3D.m:77-79): a = 2 / (1 + exp(-2 n)) - 1
+__device__ __forceinline__ double tansig(double n)
+{
+    return 2.0 / (exp(-2.0 * n) + 1.0) - 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA kernel.  K candidate size, H hidden width, NH hidden layers.
+template <int K, int H, int NH>
+__global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
+{
+    constexpr int M = K * (K + 1) / 2;
+    constexpr int DIN = K + M;
+    constexpr int S0 = (DIN + 3) / 4;      // k-steps of the input layer
+    constexpr int SH = (H + 3) / 4;        // k-steps of a hidden->hidden layer
+    constexpr int T = (H + 15) / 16;       // 16-neuron row tiles
+    constexpr int J = 2;                   // 16-candidate column tiles per pass
+    constexpr int NPASS = 64 / (16 * J);
+    static_assert(T == 4, "hidden width must be in 49..64");
+
+    __shared__ double feat[4][S0 * 4][64];  // per wave: feature-major strip of 64 candidates
+    __shared__ double ynn[4][64];           // per wave: raw network outputs
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = lane >> 4;      // MFMA k-slot / output row group
+    const int c16 = lane & 15;    // MFMA column (candidate within a 16-tile)
+    const NetDev &net = A.net;
+    const int64_t ntiles = (A.n + 255) / 256;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t c = tile * 256 + threadIdx.x;
+        const bool valid = c < A.n;
+        const int64_t cc = valid ? c : A.n - 1;
+        Cand<K> cd;
+        gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
+        const int32_t out_idx = A.orig[cc];
+
+        if (A.flags & SDPCUT_EIG) {
+            const double lam = candidate_eigmin<K>(cd);
+            if (valid) A.eig_out[out_idx] = lam;
+        }
+        if (!(A.flags & SDPCUT_NN)) continue;   // uniform branch
+
+        // ---- stage mapminmax'ed inputs (neural_net_3D.m:69-73): xp = (v - xoffset)*gain + ymin
+#pragma unroll
+        for (int i = 0; i < S0 * 4; ++i) {
+            double xp = 0.0;
+            if (i < DIN) {
+                const double v = (i < K) ? cd.x[i < K ? i : 0] : cd.q[i >= K ? i - K : 0];
+                xp = (v - net.inmap[i]) * net.inmap[DIN + i] + net.ymin;
+            }
+            feat[wave][i][lane] = xp;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            // B fragments of the input layer: B[k = 4s + q][col = candidate]
+            double bin[S0][J];
+#pragma unroll
+            for (int s = 0; s < S0; ++s)
+#pragma unroll
+                for (int j = 0; j < J; ++j) bin[s][j] = feat[wave][4 * s + q][32 * pass + 16 * j + c16];
+
+            d4 prev[T][J], cur[T][J];
+            const double *wf = net.wfrag;
+            // ---------------- input layer
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                d4 bias;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[r] = net.bias[16 * t + 4 * r + q];
+#pragma unroll
+                for (int j = 0; j < J; ++j) cur[t][j] = bias;
+#pragma unroll
+                for (int s = 0; s < S0; ++s) {
+                    const double a = wf[(t * S0 + s) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+                        cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bin[s][j], cur[t][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wf += T * S0 * 64;
+            // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
+#pragma unroll 1
+            for (int l = 1; l < NH; ++l) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) prev[t][j] = cur[t][j];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    d4 bias;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bias[r] = net.bias[l * 64 + 16 * t + 4 * r + q];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) cur[t][j] = bias;
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) {
+                        const double a = wf[(t * SH + s) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, prev[s / 4][j][s % 4],
+                                                                             cur[t][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);   // keep the next tile's weight loads from piling up
+                }
+                wf += T * SH * 64;
+            }
+            // ---------------- linear output layer: dot over this lane's 16 neurons, then the
+            // four k-slot lanes (q = 0..3) of each candidate column are summed by shuffles
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                double part = 0.0;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * t + 4 * r < H) part = fma(cur[t][j][r], net.wout[16 * t + 4 * r + q], part);
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                if (q == 0) ynn[wave][32 * pass + 16 * j + c16] = part;
+            }
+        }
+        __syncthreads();
+        {
+            // neural_net_3D.m:60-62, 81-85: y = (a + b - ymin)/gain + xoffset;  then :582
+#pragma clang fp contract(off)
+            double acc = ynn[wave][lane];
+            acc = acc + net.b_out;
+            const double y = (acc - net.y_ymin) / net.y_gain + net.y_xoffset;
+            double obj = cd.negSM;
+            obj = obj + y * cd.max_elem;
+            if (valid) A.obj_out[out_idx] = obj;
+        }
+        __syncthreads();   // feat / ynn are rewritten by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Simple kernel: lane = candidate, activations in LDS, reference operation order.
+template <int K>
+__global__ __launch_bounds__(64) void score_simple_kernel(ScoreArgs A)
+{
+    constexpr int M = K * (K + 1) / 2;
+    constexpr int DIN = K + M;
+    __shared__ double act[2][MAX_HIDDEN][64];
+    const int lane = threadIdx.x;
+    const NetDev &net = A.net;
+    const int64_t ntiles = (A.n + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t c = tile * 64 + lane;
+        const bool valid = c < A.n;
+        const int64_t cc = valid ? c : A.n - 1;
+        Cand<K> cd;
+        gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
+        const int32_t out_idx = A.orig[cc];
+        if (A.flags & SDPCUT_EIG) {
+            const double lam = candidate_eigmin<K>(cd);
+            if (valid) A.eig_out[out_idx] = lam;
+        }
+        if (!(A.flags & SDPCUT_NN)) continue;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                const double v = (i < K) ? cd.x[i < K ? i : 0] : cd.q[i >= K ? i - K : 0];
+                act[0][i][lane] = (v - net.inmap[i]) * net.inmap[DIN + i] + net.ymin;
+            }
+            int cur = 0, fan_in = DIN;
+            for (int l = 0; l < net.n_hidden; ++l) {
+                const double *W = net.raw_w[l], *b = net.raw_b[l];
+                for (int j = 0; j < net.width; ++j) {
+                    double acc = 0.0;
+                    for (int i = 0; i < fan_in; ++i) acc = acc + act[cur][i][lane] * W[j * fan_in + i];
+                    acc = acc + b[j];
+                    act[cur ^ 1][j][lane] = 2.0 / (exp(acc * -2.0) + 1.0) + -1.0;
+                }
+                cur ^= 1;
+                fan_in = net.width;
+            }
+            const double *w = net.raw_w[net.n_hidden];
+            double acc = 0.0;
+            for (int j = 0; j < fan_in; ++j) acc = acc + act[cur][j][lane] * w[j];
+            acc = acc + net.b_out;
+            const double y = (acc - net.y_ymin) / net.y_gain + net.y_xoffset;
+            double obj = cd.negSM;
+            obj = obj + y * cd.max_elem;
+            if (valid) A.obj_out[out_idx] = obj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Raw batched MLP forward on explicit inputs (the NNs.so call, batched) -- simple order.
+__global__ __launch_bounds__(64) void nn_batch_kernel(NetDev net, int64_t count, const double *in, double *out)
+{
+#pragma clang fp contract(off)
+    __shared__ double act[2][MAX_HIDDEN][64];
+    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cc = c < count ? c : count - 1;
+    const int DIN = net.d_in;
+    for (int i = 0; i < DIN; ++i)
+        act[0][i][lane] = (in[cc * DIN + i] - net.inmap[i]) * net.inmap[DIN + i] + net.ymin;
+    int cur = 0, fan_in = DIN;
+    for (int l = 0; l < net.n_hidden; ++l) {
+        const double *W = net.raw_w[l], *b = net.raw_b[l];
+        for (int j = 0; j < net.width; ++j) {
+            double acc = 0.0;
+            for (int i = 0; i < fan_in; ++i) acc = acc + act[cur][i][lane] * W[j * fan_in + i];
+            acc = acc + b[j];
+            act[cur ^ 1][j][lane] = 2.0 / (exp(acc * -2.0) + 1.0) + -1.0;
+        }
+        cur ^= 1;
+        fan_in = net.width;
+    }
+    const double *w = net.raw_w[net.n_hidden];
+    double acc = 0.0;
+    for (int j = 0; j < fan_in; ++j) acc = acc + act[cur][j][lane] * w[j];
+    acc = acc + net.b_out;
+    if (c < count) out[c] = (acc - net.y_ymin) / net.y_gain + net.y_xoffset;
+}
+
+// ------------------------------------------------------------------------------------------
+// Eigen-cut rows of selected candidates (cut_select_qp.py:737-750), one lane per cut.
+template <int K>
+__device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *vars, int32_t nv, int64_t L,
+                                            double *lam_out, double *coef, double *rhs, int64_t *cols)
+{
+    constexpr int M = K * (K + 1) / 2;
+    constexpr int D = K + 1;
+    double x[K], X[M];
+    int32_t s[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+        s[a] = s5[a];
+        x[a] = vars[L + s[a]];
+        cols[a] = L + s[a];
+    }
+    {
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const int32_t rowbase = nv * s[a] - (s[a] * (s[a] + 1)) / 2;
+#pragma unroll
+            for (int b = a; b < K; ++b) {
+                X[m] = vars[rowbase + s[b]];
+                cols[K + m] = rowbase + s[b];
+                ++m;
+            }
+        }
+    }
+    double a[D][D], v[D][D];
+    fill_lifted<K>(a, x, X);
+    jacobi_eig<D, true>(a, v);
+    // eigenvector of the smallest eigenvalue (first minimum, like LAPACK's ascending order)
+    double lam = a[0][0];
+    double ev[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) ev[i] = v[i][0];
+#pragma unroll
+    for (int j = 1; j < D; ++j) {
+        const bool less = a[j][j] < lam;
+        lam = less ? a[j][j] : lam;
+#pragma unroll
+        for (int i = 0; i < D; ++i) ev[i] = less ? v[i][j] : ev[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) ev[i] = (fabs(ev[i]) <= -SDPCUT_NEG_EIGVAL) ? 0.0 : ev[i];  // :744
+    {
+#pragma clang fp contract(off)
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = (i > 1 ? i : 1); j < D; ++j) {     // :745-746
+                coef[m++] = (i != j) ? ev[i] * ev[j] * 2 : ev[i] * ev[j];
+            }
+        *rhs = -ev[0] * ev[0];
+    }
+    *lam_out = lam;
+}
+
+__global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64_t *idx, const int32_t *set5,
+                                                      const int32_t *ks, const double *vars, int32_t nv,
+                                                      int64_t L, double *lam, double *coef, double *rhs,
+                                                      int64_t *cols, int32_t *ks_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const int64_t c = idx[i];
+    const int k = ks[c];
+    const int32_t *s5 = set5 + c * 5;
+    double *co = coef + i * SDPCUT_ROW_LD;
+    int64_t *cl = cols + i * SDPCUT_ROW_LD;
+    for (int m = 0; m < SDPCUT_ROW_LD; ++m) { co[m] = 0.0; cl[m] = -1; }
+    ks_out[i] = k;
+    switch (k) {
+    case 2: cut_row_one<2>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    case 3: cut_row_one<3>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    case 4: cut_row_one<4>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    default: cut_row_one<5>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched full eigen-decomposition of explicit sub-matrices (twin of _get_eigendecomp).
+template <int K>
+__global__ __launch_bounds__(64) void eig_batch_kernel(int64_t count, const double *xr, const double *Xr,
+                                                       double *vals, double *vecs)
+{
+    constexpr int M = K * (K + 1) / 2;
+    constexpr int D = K + 1;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double x[K], X[M];
+#pragma unroll
+    for (int a = 0; a < K; ++a) x[a] = xr[i * K + a];
+#pragma unroll
+    for (int m = 0; m < M; ++m) X[m] = Xr[i * M + m];
+    double a[D][D], v[D][D];
+    fill_lifted<K>(a, x, X);
+    jacobi_eig<D, true>(a, v);
+    double w[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) w[j] = a[j][j];
+    // ascending sort of the eigenpairs (odd-even transposition network, static indices)
+#pragma unroll
+    for (int round = 0; round < D; ++round)
+#pragma unroll
+        for (int j = round & 1; j + 1 < D; j += 2) {
+            const bool sw = w[j + 1] < w[j];
+            const double lo = sw ? w[j + 1] : w[j], hi = sw ? w[j] : w[j + 1];
+            w[j] = lo; w[j + 1] = hi;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                const double p = v[r][j], qv = v[r][j + 1];
+                v[r][j] = sw ? qv : p;
+                v[r][j + 1] = sw ? p : qv;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < D; ++j) vals[i * D + j] = w[j];
+    if (vecs) {
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int j = 0; j < D; ++j) vecs[(i * D + r) * D + j] = v[r][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fragment-map probe: C[16][16] = A[16][4] * B[4][16] with the maps the MLP kernel assumes.
+__global__ __launch_bounds__(64) void mfma_probe_kernel(const double *Am, const double *Bm, double *Cm)
+{
+    const int lane = threadIdx.x;
+    const double a = Am[(lane & 15) * 4 + (lane >> 4)];   // A[row = lane&15][k = lane>>4]
+    const double b = Bm[(lane >> 4) * 16 + (lane & 15)];  // B[k = lane>>4][col = lane&15]
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cm[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
+{
+    int64_t cap = (int64_t)h->n_cu * per_cu;
+    int64_t g = ntiles < cap ? ntiles : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+template <int K>
+static int launch_score_k(sdpcut_ctx *h, uint32_t flags)
+{
+    const Bucket &b = h->bucket[K];
+    if (b.n == 0) return 0;
+    ScoreArgs A;
+    A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
+    A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
+    A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
+    A.net = h->net[K].dev;
+    const NetDev &nd = A.net;
+    bool mfma_ok = false;
+    if (flags & SDPCUT_NN) {
+        if (!h->net[K].set) return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
+        mfma_ok = (K == 2 && nd.width == 64 && nd.n_hidden == 3) || (K == 3 && nd.width == 50 && nd.n_hidden == 3) ||
+                  (K == 4 && nd.width == 50 && nd.n_hidden == 3) || (K == 5 && nd.width == 64 && nd.n_hidden == 4);
+    } else {
+        mfma_ok = true;   // eig only: the network part of the kernel is skipped
+    }
+    if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
+        const int64_t ntiles = (b.n + 255) / 256;
+        const int grid = grid_for(h, ntiles, 8);
+        if (K == 2) hipLaunchKernelGGL((score_mfma_kernel<2, 64, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 3) hipLaunchKernelGGL((score_mfma_kernel<3, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 4) hipLaunchKernelGGL((score_mfma_kernel<4, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 5) hipLaunchKernelGGL((score_mfma_kernel<5, 64, 4>), dim3(grid), dim3(256), 0, h->stream, A);
+    } else {
+        const int64_t ntiles = (b.n + 63) / 64;
+        const int grid = grid_for(h, ntiles, 16);
+        hipLaunchKernelGGL((score_simple_kernel<K>), dim3(grid), dim3(64), 0, h->stream, A);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_score(sdpcut_ctx *h, uint32_t flags)
+{
+    int rc;
+    if ((rc = launch_score_k<2>(h, flags))) return rc;
+    if ((rc = launch_score_k<3>(h, flags))) return rc;
+    if ((rc = launch_score_k<4>(h, flags))) return rc;
+    if ((rc = launch_score_k<5>(h, flags))) return rc;
+    return 0;
+}
+
+int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_idx, double *d_lam, double *d_coef,
+                    double *d_rhs, int64_t *d_cols, int32_t *d_ks)
+{
+    if (count == 0) return 0;
+    const int grid = (int)((count + 63) / 64);
+    hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_idx, h->d_set_orig, h->d_k,
+                       h->d_vars, h->nb_vars, h->L, d_lam, d_coef, d_rhs, d_cols, d_ks);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
+                     double *d_vals, double *d_vecs)
+{
+    if (count == 0) return 0;
+    const int grid = (int)((count + 63) / 64);
+    switch (k) {
+    case 2: hipLaunchKernelGGL((eig_batch_kernel<2>), dim3(grid), dim3(64), 0, h->stream, count, d_x, d_X, d_vals, d_vecs); break;
+    case 3: hipLaunchKernelGGL((eig_batch_kernel<3>), dim3(grid), dim3(64), 0, h->stream, count, d_x, d_X, d_vals, d_vecs); break;
+    case 4: hipLaunchKernelGGL((eig_batch_kernel<4>), dim3(grid), dim3(64), 0, h->stream, count, d_x, d_X, d_vals, d_vecs); break;
+    case 5: hipLaunchKernelGGL((eig_batch_kernel<5>), dim3(grid), dim3(64), 0, h->stream, count, d_x, d_X, d_vals, d_vecs); break;
+    default: return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
+    }
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out)
+{
+    if (count == 0) return 0;
+    const int grid = (int)((count + 63) / 64);
+    hipLaunchKernelGGL(nn_batch_kernel, dim3(grid), dim3(64), 0, h->stream, h->net[k].dev, count, d_in, d_out);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_mfma_probe(sdpcut_ctx *h, const double *d_A, const double *d_B, double *d_C)
+{
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, h->stream, d_A, d_B, d_C);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,139 @@
+"""Candidate sets sharded over several GPUs (SURVEY.md section 8 e).
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).  Candidates are
+independent, so each rank scores a contiguous shard with its own C-ABI handle and there is
+exactly one exchange step per ranking: an all-gather of the per-shard head
+(sel_size x (score fp64, global id int64) = 16 B per entry, <= 640 KB at 8 ranks) followed by a
+replicated merge keyed (score descending, id ascending) -- the same order the reference's
+stable sort gives on one list (cut_select_qp.py:601, :625, :653).  Counters are all-reduced.
+
+The combined strategy's early-exit scan (cut_select_qp.py:606-623) is merged class by class
+(STRONG / LOW / REST partial rankings of the C-ABI), which reproduces the head of the
+single-list result; see :meth:`ShardedSelector.select`.
+
+With the "gloo" backend (CPU rehearsal of the choreography, used by the tests) the gathered
+buffers are staged through host memory; the ranking and the merge still run on the device.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi
+
+_BIG_M = 1000.0
+_PAD_ID = np.iinfo(np.int64).max
+
+
+class DeviceOps(object):
+    """The two device operations the selector needs, on a :class:`_capi.Scorer`."""
+
+    def __init__(self, scorer, device):
+        self.scorer, self.device = scorer, device
+        # run the library on torch's current stream: its kernels, torch's copies and the
+        # collectives torch enqueues are then ordered without host synchronisation
+        scorer.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def local_head(self, strat, sel_size, count, want_secondary=False):
+        """-> (scores[count] fp64, ids[count] int64, secondary[count] or None, n_total, counters);
+        device tensors padded with (-inf, PAD, -inf).  secondary = obj_improve of each entry."""
+        scores = torch.full((count,), float("-inf"), dtype=torch.float64, device=self.device)
+        ids = torch.full((count,), _PAD_ID, dtype=torch.int64, device=self.device)
+        sec = torch.full((count,), float("-inf"), dtype=torch.float64, device=self.device) if want_secondary else None
+        tmp_s = torch.empty(count, dtype=torch.float64, device=self.device)
+        tmp_i = torch.empty(count, dtype=torch.int64, device=self.device)
+        w, total, _, counters = self.scorer.rank_device(strat, sel_size, count, tmp_i.data_ptr(), tmp_s.data_ptr())
+        if w:
+            scores[:w], ids[:w] = tmp_s[:w], tmp_i[:w]
+            if want_secondary:
+                tmp_o = torch.empty(w, dtype=torch.float64, device=self.device)
+                self.scorer.gather_scores_device(w, tmp_i.data_ptr(), None, tmp_o.data_ptr())
+                sec[:w] = tmp_o
+        return scores, ids, sec, total, counters
+
+    def merge(self, scores, ids, count_out, secondary=None):
+        out_s = torch.empty(count_out, dtype=torch.float64, device=self.device)
+        out_i = torch.empty(count_out, dtype=torch.int64, device=self.device)
+        self.scorer.merge_topk_device(scores.numel(), scores.data_ptr(), ids.data_ptr(), count_out,
+                                      out_s.data_ptr(), out_i.data_ptr(),
+                                      secondary.data_ptr() if secondary is not None else None)
+        return out_s, out_i
+
+
+class ShardedSelector(object):
+    """Global top-``sel_size`` selection over candidate shards, replicated on every rank."""
+
+    def __init__(self, ops, n_local, group=None):
+        self.ops, self.group = ops, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n_local = int(n_local)
+        self.n_global = self._sum(self.n_local)
+
+    # -- collectives ---------------------------------------------------------------------
+    def _sum(self, *vals):
+        if self.world == 1:
+            return vals[0] if len(vals) == 1 else list(vals)
+        t = torch.tensor(vals, dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(self.ops.device)
+        dist.all_reduce(t, group=self.group)
+        out = [int(v) for v in t.cpu()]
+        return out[0] if len(vals) == 1 else out
+
+    def _all_gather(self, t):
+        if self.world == 1:
+            return t
+        if dist.get_backend(self.group) == "nccl":
+            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            return out
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(self.world)]
+        dist.all_gather(parts, host, group=self.group)
+        return torch.cat(parts).to(t.device)
+
+    def _global_head(self, strat, sel_size, count, want_secondary=False):
+        """Merged head of one ranking: (scores, ids, global list length, summed counters)."""
+        s, i, sec, total, cnt = self.ops.local_head(strat, sel_size, count, want_secondary)
+        g_total, nv, strong, viol, npos = self._sum(total, cnt["nb_violated"], cnt["strong"], cnt["violated"],
+                                                    cnt["nb_positive"])
+        if self.world > 1:
+            sec_all = self._all_gather(sec) if sec is not None else None
+            s, i = self.ops.merge(self._all_gather(s), self._all_gather(i), count, sec_all)
+        valid = min(count, g_total)
+        return s[:valid], i[:valid], g_total, dict(nb_violated=nv, strong=strong, violated=viol, nb_positive=npos)
+
+    # -- selection -----------------------------------------------------------------------
+    def select(self, strat, sel_size):
+        """-> dict(ids int64 tensor, scores fp64 tensor, new_strat, n_total, counters): the
+        first min(sel_size, length) entries of the reference's rank list over ALL shards.
+
+        Combined strategy: the reference walks the obj_improve-sorted list until it has seen
+        sel_size "strong" (positive and violated) entries (cut_select_qp.py:606-623).
+          1. merged per-shard heads of the STRONG class give the global number of strong
+             entries and, if there are at least sel_size, the answer itself: the head of the
+             re-sorted list is exactly those entries, +BIG_M, in obj_improve order;
+          2. otherwise the scan visits every entry on every shard, so each shard's own combined
+             ranking with an unreachable quota is a sub-list of the global one; heads are merged
+             with obj_improve as secondary key (the second sort at :625 is stable w.r.t. the
+             first at :601)."""
+        sel_size = min(int(sel_size), self.n_global)
+        if strat in (1, 2):
+            s, i, total, cnt = self._global_head(strat, sel_size, sel_size)
+            return dict(ids=i, scores=s, new_strat=strat, n_total=total, counters=cnt)
+        if strat != 4:
+            raise ValueError("strategy must be 1, 2 or 4")
+        if sel_size == 0:
+            e = torch.empty(0, device=self.ops.device)
+            return dict(ids=e.to(torch.int64), scores=e.to(torch.float64), new_strat=4, n_total=self.n_global,
+                        counters=dict(strong=0, violated=0))
+        s, i, n_strong, _ = self._global_head(_capi.PART_STRONG, 0, sel_size)
+        if n_strong >= sel_size:
+            strong = violated = sel_size
+            ids, scores = i, s + _BIG_M
+        else:
+            quota = self.n_global + 1                     # never reached: every entry is visited
+            scores, ids, _, cnt = self._global_head(4, quota, sel_size, want_secondary=True)
+            strong, violated = cnt["strong"], cnt["violated"]
+        new_strat = 1 if strong / sel_size < violated / self.n_global else 4     # cut_select_qp.py:630
+        return dict(ids=ids, scores=scores, new_strat=new_strat, n_total=self.n_global,
+                    counters=dict(strong=strong, violated=violated))
