@@ -64,6 +64,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # PyTorch-ROCm bundles its own HIP/HSA runtime (same SONAME libamdhip64.so.7).  A process
+    # must hold exactly one of them: import torch first so that this library binds to the
+    # runtime torch (device memory, streams, torch.distributed/RCCL) already brought in.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise RuntimeError(
             "%s not found: build it with `python -m sdpcutsel_via_nn_amd.build` "

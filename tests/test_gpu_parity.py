@@ -375,6 +375,8 @@ def test_full_size_kernels_agree(full_c2, scorer):
         eig2, obj2 = scorer.get_scores()
     finally:
         scorer.set_option(_capi.OPT_KERNEL, _capi.KERNEL_MFMA)
+        scorer.set_point(wl["vars_values"])                # leave the module fixture's scores on the device
+        scorer.score(_capi.EIG | _capi.NN)
     assert np.array_equal(eig, eig2)                       # same Jacobi code in both kernels
     assert np.abs(obj - obj2).max() <= 1e-10 * np.abs(obj).max()
 
@@ -393,3 +395,74 @@ def test_merge_topk_device(lib, scorer):
     ref = np.lexsort((ids, -scores))[:5000]
     assert np.array_equal(oi.cpu().numpy(), ids[ref])
     assert np.array_equal(os_.cpu().numpy(), scores[ref])
+
+
+def test_merge_topk_device_with_secondary_key(scorer):
+    import torch
+    rng = np.random.default_rng(6)
+    scores = rng.integers(0, 20, 30000).astype(np.float64)
+    sec = rng.integers(-5, 5, 30000).astype(np.float64)
+    ids = rng.permutation(10 ** 6)[:30000].astype(np.int64)
+    ds, dq, di = (torch.from_numpy(a).cuda() for a in (scores, sec, ids))
+    os_ = torch.empty(30000, dtype=torch.float64, device="cuda")
+    oi = torch.empty(30000, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    scorer.merge_topk_device(30000, ds.data_ptr(), di.data_ptr(), 30000, os_.data_ptr(), oi.data_ptr(), dq.data_ptr())
+    scorer.synchronize()
+    ref = np.lexsort((ids, -sec, -scores))
+    assert np.array_equal(oi.cpu().numpy(), ids[ref])
+    assert np.array_equal(os_.cpu().numpy(), scores[ref])
+
+
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_sharded_selector_single_rank_equals_rank(full_c2, scorer, oracle, strat):
+    """world_size 1: the sharded selection path (partial STRONG ranking, device buffers,
+    gather of secondary keys) returns the head of the plain ranking."""
+    import torch
+    from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector
+    wl, eig, obj = full_c2
+    ops = DeviceOps(scorer, torch.device("cuda", 0))
+    try:
+        sel = ShardedSelector(ops, 10 ** 6)
+        for sel_size in (5000, 37):
+            r = sel.select(strat, sel_size)
+            order, score, new_strat, cnt = oracle.rank_arrays(strat, obj, eig, sel_size)
+            k = min(sel_size, order.shape[0])
+            assert np.array_equal(r["ids"].cpu().numpy(), order[:k])
+            assert np.array_equal(r["scores"].cpu().numpy(), score[:k] + 0.0)
+            assert r["new_strat"] == new_strat
+    finally:
+        scorer.set_stream(None)
+
+
+def test_sharded_selector_sparse_strong_regime(scorer, oracle):
+    """Combined strategy when fewer than sel_size candidates are positive and violated: every
+    entry is visited and the head continues with the -lambda_min and the remaining classes."""
+    import torch
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector
+    wl = synthetic.make_workload(nb_vars=40, k=3, count=30000, seed=21)
+    # objective scaled down: the MLP estimate rarely beats the current value -> few positives
+    scorer.set_instance(40, wl["Q_arr"])
+    scorer.set_candidates(wl["set_inds"], wl["ks"])
+    x = np.full(40, 0.5)
+    iu = np.triu_indices(40)
+    rng = np.random.default_rng(2)
+    X = np.where(rng.uniform(size=iu[0].shape[0]) < 0.5, 0.25, np.minimum(x[iu[0]], x[iu[1]]))
+    vv = np.concatenate([X, x])
+    scorer.set_point(vv)
+    scorer.score(_capi.EIG | _capi.NN)
+    eig, obj = scorer.get_scores()
+    ops = DeviceOps(scorer, torch.device("cuda", 0))
+    try:
+        sel = ShardedSelector(ops, 30000)
+        n_strong = int(((obj > 0) & (eig < -1e-15)).sum())
+        for sel_size in (n_strong + 50, 29000, max(n_strong - 3, 1)):
+            r = sel.select(4, sel_size)
+            order, score, new_strat, cnt = oracle.rank_arrays(4, obj, eig, sel_size)
+            assert np.array_equal(r["ids"].cpu().numpy(), order[:sel_size])
+            assert np.array_equal(r["scores"].cpu().numpy(), score[:sel_size] + 0.0)
+            assert r["new_strat"] == new_strat
+            assert r["counters"]["strong"] == cnt["strong"] and r["counters"]["violated"] == cnt["violated"]
+    finally:
+        scorer.set_stream(None)
