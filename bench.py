@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--kernel", choices=["mfma", "simple"], default="mfma")
+    ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     args = ap.parse_args()
@@ -91,7 +91,7 @@ def main():
         wl["Q_arr"], wl["vars_values"] = wl0[0], wl0[1]
     sc = _capi.Scorer(local_rank)
     sc.set_option(_capi.OPT_TIMING, 1)
-    sc.set_option(_capi.OPT_KERNEL, _capi.KERNEL_MFMA if args.kernel == "mfma" else _capi.KERNEL_SIMPLE)
+    sc.set_option(_capi.OPT_KERNEL, {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[args.kernel])
     sc.set_network(K, *networks.load_network(K))
     sc.set_instance(NB_VARS, wl["Q_arr"])
     sc.set_candidates(wl["set_inds"], wl["ks"], global_base=rank * N_PER_GPU)
@@ -145,7 +145,7 @@ def main():
                        "kernel": args.kernel, "strategy": 4},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "score_mfma_kernel<3,50,3>" if args.kernel == "mfma" else "score_simple_kernel<3>",
+                         "kernel": {"mfma": "score_mfma_kernel<3,50,3>", "valu": "score_valu_kernel<3,50,3>", "simple": "score_simple_kernel<3>"}[args.kernel],
                          "kernel_ms": k_ms, "flops_per_candidate": FLOPS_PER_CAND[K],
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_candidate": BYTES_PER_CAND[K]},

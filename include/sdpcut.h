@@ -53,7 +53,7 @@ enum { SDPCUT_STRAT_FEAS = 1, SDPCUT_STRAT_OPT = 2, SDPCUT_STRAT_COMB = 4 };
 enum { SDPCUT_PART_STRONG = 104 };
 
 /* kernel variants for sdpcut_set_option(SDPCUT_OPT_KERNEL, ...) */
-enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1 };
+enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 };
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2 };
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libsdpcut_hip.so")
 EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
 PART_STRONG = 104
-KERNEL_MFMA, KERNEL_SIMPLE = 0, 1
+KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
 OPT_KERNEL, OPT_TIMING = 1, 2
 ROW_LD = 20
 

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdpcut_hip.so")
-SOURCES = ["score.hip", "rank.hip", "capi.hip"]
-HEADERS = ["common.h", "jacobi.h", os.path.join("..", "..", "include", "sdpcut.h")]
+SOURCES = ["score.hip", "rank.hip", "topk.hip", "capi.hip"]
+HEADERS = ["common.h", "jacobi.h", "keys.h", os.path.join("..", "..", "include", "sdpcut.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value"]
@@ -37,16 +37,16 @@ def build(force=False, verbose=True):
         if force or _newer(o, [s] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd)))
+                print(" ".join(cmd), file=sys.stderr, flush=True)
+            procs.append((cmd, subprocess.Popen(cmd, stdout=sys.stderr)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or procs or _newer(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+            print(" ".join(cmd), file=sys.stderr, flush=True)
+        subprocess.check_call(cmd, stdout=sys.stderr)
     return LIB
 
 

@@ -78,6 +78,7 @@ int sdpcut_destroy(sdpcut_handle h)
     hipStreamSynchronize(h->stream);
     free_candidates(h);
     free_rank_ws(h);
+    free_topk_ws(h);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -91,7 +92,7 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     if (!h) return SDPCUT_EINVAL;
     switch (option) {
     case SDPCUT_OPT_KERNEL:
-        if (value != SDPCUT_KERNEL_MFMA && value != SDPCUT_KERNEL_SIMPLE)
+        if (value != SDPCUT_KERNEL_MFMA && value != SDPCUT_KERNEL_SIMPLE && value != SDPCUT_KERNEL_VALU)
             return sdpcut_fail(h, SDPCUT_EINVAL, "unknown kernel variant");
         h->kernel_variant = (int)value;
         return SDPCUT_OK;
@@ -195,6 +196,23 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
             fan = H;
         }
     }
+    // scalar-operand packing of the VALU kernel: [layer][j/8][i][j%8]
+    const int NBv = (H + 7) / 8;
+    // (+16: the kernel streams the weights in 16-double batches and may read past an odd fan-in)
+    const size_t o_wvalu = reserve((size_t)NBv * 8 * ((size_t)d_in + (size_t)(nh - 1) * H) + 16);
+    {
+        size_t o = o_wvalu;
+        int fan = d_in;
+        for (int l = 0; l < nh; ++l) {
+            for (int jb = 0; jb < NBv; ++jb)
+                for (int i = 0; i < fan; ++i)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = jb * 8 + jj;
+                        blob[o++] = (j < H) ? W[l][(size_t)j * fan + i] : 0.0;
+                    }
+            fan = H;
+        }
+    }
     NetHost &nh_ = h->net[k];
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(nh_.d_blob);
@@ -209,6 +227,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
     d.bias = nh_.d_blob + o_bias;
     d.wout = nh_.d_blob + o_wout;
     d.wfrag = nh_.d_blob + o_frag;
+    d.wvalu = nh_.d_blob + o_wvalu;
     for (int l = 0; l < n_layers; ++l) { d.raw_w[l] = nh_.d_blob + o_rw[l]; d.raw_b[l] = nh_.d_blob + o_rb[l]; }
     d.ymin = ymin; d.b_out = B[nh][0]; d.y_ymin = y_ymin; d.y_gain = y_gain; d.y_xoffset = y_xoffset;
     nh_.set = true;
@@ -543,6 +562,7 @@ int sdpcut_last_timing(sdpcut_handle h, double *ms, int n)
     float a = 0.f, b = 0.f;
     if (hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess) a = -1.f;
     if (hipEventElapsedTime(&b, h->ev[2], h->ev[3]) != hipSuccess) b = -1.f;
+    (void)hipGetLastError();   // an unrecorded pair is not an error of this library: clear the sticky code
     ms[0] = a;
     if (n > 1) ms[1] = b;
     return SDPCUT_OK;

@@ -20,6 +20,7 @@ struct NetDev {
     int width;             // hidden width (all hidden layers equal: 64 or 50)
     int s0, sh;            // k-steps (of 4) of the first / the other hidden layers
     const double *wfrag;   // MFMA A-fragments: layer-major, then [t][s][lane]
+    const double *wvalu;   // scalar-operand packing: layer-major, then [j/8][i][j%8], zero padded
     const double *bias;    // [n_hidden][64] zero padded
     const double *wout;    // [64] zero padded output weights
     const double *inmap;   // xoffset[d_in] | gain[d_in]
@@ -74,6 +75,10 @@ struct sdpcut_ctx {
     int64_t *d_counters = nullptr; // [8]
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    // top-k select workspace (topk.hip)
+    void *d_topk_ws = nullptr;
+    uint64_t *d_sel_key = nullptr;
+    uint32_t *d_sel_idx = nullptr;
     // small staging
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -108,3 +113,8 @@ int merge_topk_on_device(sdpcut_ctx *h, int64_t count, const double *d_scores, c
 int gather_scores_on_device(sdpcut_ctx *h, int64_t count, const int64_t *d_ids, double *d_eig_out, double *d_obj_out);
 int rank_fetch_on_device(sdpcut_ctx *h, int64_t offset, int64_t count, int64_t *d_idx_out, double *d_score_out);
 void free_rank_ws(sdpcut_ctx *h);
+
+// topk.hip
+int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
+                          double *d_score_out, int64_t cnt[4]);
+void free_topk_ws(sdpcut_ctx *h);

@@ -14,19 +14,7 @@
 #include <rocprim/functional.hpp>
 
 #include "common.h"
-
-// order-preserving map double -> u64 (ascending); -0.0 is folded onto +0.0 first because
-// Python compares them equal
-__device__ __forceinline__ uint64_t key_of(double s)
-{
-    const uint64_t u = (uint64_t)__double_as_longlong(s + 0.0);
-    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double score_of(uint64_t k)
-{
-    const uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
+#include "keys.h"
 
 // counters: [0] nb_violated  [1] strong  [2] violated_in_scan  [3] nb_positive
 __global__ void keys_first_kernel(int strat, int64_t n, const double *eig, const double *obj, uint64_t *key,
@@ -189,6 +177,48 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     if (sel_size > n) sel_size = n;                 // cut_select_qp.py:551
     if (sel_size < 0) sel_size = 0;
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- fast path: the caller wants only a short head (the loop consumes <= 5000 entries,
+    // _SDP_CUTS_PER_ROUND_MAX): radix select + small sort instead of sorting all N (topk.hip)
+    if (n > 0 && max_out >= 1 && max_out <= 8192) {
+        int mode = 0;
+        int64_t k = max_out;
+        double add = 0.0;
+        if (strat == SDPCUT_STRAT_FEAS) mode = 1;
+        else if (strat == SDPCUT_STRAT_OPT) mode = 2;
+        else if (strat == SDPCUT_PART_STRONG) mode = 3;
+        else if (strat == SDPCUT_STRAT_COMB && sel_size >= 1 && max_out <= sel_size) {
+            // combined scan, common regime: at least sel_size candidates are positive AND violated.
+            // The scan stops after sel_size of them; the re-sorted list starts with exactly those,
+            // +BIG_M, in obj_improve order (cut_select_qp.py:606-625).  Verified below via the class size.
+            mode = 3;
+            add = SDPCUT_BIG_M;
+        }
+        if (mode) {
+            int64_t c4[4] = {0, 0, 0, 0};
+            rc = topk_select_on_device(h, mode, k, add, d_idx_out, d_score_out, c4);
+            if (rc) return rc;
+            const bool comb = strat == SDPCUT_STRAT_COMB;
+            if (!comb || c4[0] >= sel_size) {
+                const int64_t total = (strat == SDPCUT_STRAT_OPT || comb) ? n : c4[0];
+                const int64_t w = total < max_out ? total : max_out;
+                h->last_total = -1;                     // only the head exists: nothing to fetch later
+                if (n_written) *n_written = w;
+                if (n_total) *n_total = total;
+                cnt[0] = c4[1]; cnt[3] = c4[2];
+                if (strat == SDPCUT_STRAT_FEAS || strat == SDPCUT_PART_STRONG) cnt[0] = (strat == SDPCUT_STRAT_FEAS) ? c4[0] : c4[0];
+                if (comb) { cnt[1] = sel_size; cnt[2] = sel_size; }
+                if (new_strat) {
+                    *new_strat = strat;
+                    if (comb && (double)cnt[1] / (double)sel_size < (double)cnt[2] / (double)n) *new_strat = SDPCUT_STRAT_FEAS;
+                }
+                if (counters_out)
+                    for (int i = 0; i < 4; ++i) counters_out[i] = cnt[i];
+                return 0;
+            }
+            // fewer strong candidates than sel_size: every entry is visited -> general path below
+            for (int i = 0; i < 8; ++i) cnt[i] = 0;
+        }
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 8 * sizeof(int64_t), h->stream));
     const uint64_t *fkey = h->d_key_b;
     const uint32_t *fval = h->d_val_b;

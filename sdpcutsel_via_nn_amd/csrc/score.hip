@@ -106,9 +106,43 @@ __device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
 }
 
 // tansig as MATLAB defines it (neural_net_3D.m:77-79): a = 2 / (1 + exp(-2 n)) - 1
-__device__ __forceinline__ double tansig(double n)
+__device__ __forceinline__ double tansig_lib(double n)
 {
     return 2.0 / (exp(-2.0 * n) + 1.0) - 1.0;
+}
+
+// The same formula with a branch-free exp and reciprocal (29 fp64 instructions instead of the
+// ~36 of the library route; profiles/r01_ubench_fp64_rates.txt).  y = -2n is clamped to
+// [-80, 80], where 2/(1+e^y)-1 has long saturated to -1 / +1 in fp64; exp(y) = 2^k * p(r) with
+// k = rint(y log2 e), r = y - k ln2 in two pieces (|r| <= 0.3466) and the degree-13 Taylor
+// polynomial (truncation 4e-18); the reciprocal is v_rcp_f64 (4.5e-8) + two Newton steps.
+// Absolute error vs the exact formula <= 4e-16, the same class as the library route.
+__device__ __forceinline__ double tansig(double n)
+{
+    double y = -2.0 * n;
+    y = fmin(fmax(y, -80.0), 80.0);
+    const double k = rint(y * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, y);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.60590438368216145994e-10;              // 1/13!
+    p = fma(p, r, 2.08767569878680989792e-09);          // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);          // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);          // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);          // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);          // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);          // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);          // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);          // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);          // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);          // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double d = ldexp(p, (int)k) + 1.0;
+    double q = __builtin_amdgcn_rcp(d);
+    q = fma(fma(-d, q, 1.0), q, q);
+    q = fma(fma(-d, q, 1.0), q, q);
+    return fma(2.0, q, -1.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,6 +287,134 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             if (valid) A.obj_out[out_idx] = obj;
         }
         __syncthreads();   // feat / ynn are rewritten by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// VALU kernel: lane = candidate, activations in registers, weights as SCALAR operands.
+//
+// On gfx950 v_mfma_f64_16x16x4_f64 and v_fma_f64 share the fp64 datapath: they do not overlap
+// (profiles/r01_ubench_mfma_valu_overlap.txt: MFMA-only 0.85 ms, FMA-only 0.94 ms, both on one
+// SIMD 1.81 ms) and peak at the same 78.6 TFLOP/s.  The MFMA form pads 50 neurons to 64 rows
+// (26 % wasted FLOPs); here every fp64 FMA is a useful one.  Weights are wave-uniform, so they
+// are read through the scalar cache (s_load_dwordx16 = 8 weights) and enter v_fma_f64 as SGPR
+// operands: no LDS, no vector memory traffic in the MLP at all.  Eight output neurons are
+// accumulated at once (8 independent FMA chains hide the fp64 latency); weights are packed
+// host-side as [layer][j/8][i][j%8] so that each (block, i) is one 64-byte scalar load.
+typedef const __attribute__((address_space(4))) double *cdouble_p;   // constant AS => SMEM loads
+
+// Scalar loads return out of order, so the only usable wait is lgkmcnt(0): the weight stream is
+// software-pipelined in batches of two input steps (2 x s_load_dwordx16 = 16 weights): batch
+// g+1 is issued, then the 16 FMAs of batch g run while it is in flight.  The sched_barriers pin
+// that order (left alone, hipcc issues each load right in front of its first use and eats the
+// full scalar-cache latency every 8 FMAs).
+template <int FAN, int H>
+__device__ __forceinline__ void dense_tansig(cdouble_p wv, cdouble_p bias, const double (&in)[FAN], double (&out)[H])
+{
+    constexpr int JB = 8, NB = (H + JB - 1) / JB;
+    constexpr int NBAT = (FAN + 1) / 2;          // batches of two input steps per output block
+    double wa[2 * JB], wb[2 * JB];            // the two weight buffers (SGPRs)
+#pragma unroll
+    for (int t = 0; t < 2 * JB; ++t) wa[t] = wv[t];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        double acc[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) acc[jj] = bias[jb * JB + jj];
+#pragma unroll
+        for (int bt = 0; bt < NBAT; ++bt) {
+            const int g = jb * NBAT + bt;             // global batch number: its parity picks the buffer
+            const bool last = (jb == NB - 1) && (bt == NBAT - 1);
+            const int jn = (bt + 1 < NBAT) ? jb : jb + 1, bn = (bt + 1 < NBAT) ? bt + 1 : 0;
+            // lgkmcnt(0) BEFORE the next batch is issued: the current buffer is complete and the
+            // new loads stay in flight during the FMAs below (0xc07f = vmcnt/expcnt untouched)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (!last) {
+#pragma unroll
+                for (int t = 0; t < 2 * JB; ++t) {
+                    const double v = wv[(jn * FAN + 2 * bn) * JB + t];
+                    if (g & 1) wa[t] = v; else wb[t] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = 2 * bt + u;
+                if (i < FAN) {
+#pragma unroll
+                    for (int jj = 0; jj < JB; ++jj)
+                        if (jb * JB + jj < H)
+                            acc[jj] = fma(in[i < FAN ? i : 0], (g & 1) ? wb[u * JB + jj] : wa[u * JB + jj], acc[jj]);
+                }
+            }
+            if (bt == NBAT - 1) {
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj)
+                    if (jb * JB + jj < H) out[jb * JB + jj] = tansig(acc[jj]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int K, int H, int NH>
+__global__ __launch_bounds__(256, (H > 56 ? 1 : 2)) void score_valu_kernel(ScoreArgs A)
+{
+    constexpr int M = K * (K + 1) / 2;
+    constexpr int DIN = K + M;
+    constexpr int NB = (H + 7) / 8;
+    const NetDev &net = A.net;
+    const int64_t ntiles = (A.n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t c = tile * 256 + threadIdx.x;
+        const bool valid = c < A.n;
+        const int64_t cc = valid ? c : A.n - 1;
+        Cand<K> cd;
+        gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
+        const int32_t out_idx = A.orig[cc];
+        double lam = 0.0;
+        if (A.flags & SDPCUT_EIG) lam = candidate_eigmin<K>(cd);
+        double obj = 0.0;
+        if (A.flags & SDPCUT_NN) {
+            cdouble_p inmap = (cdouble_p)net.inmap;
+            double in[DIN];
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                const double v = (i < K) ? cd.x[i < K ? i : 0] : cd.q[i >= K ? i - K : 0];
+                in[i] = (v - inmap[i]) * inmap[DIN + i] + net.ymin;
+            }
+            double a[H];
+            dense_tansig<DIN, H>((cdouble_p)net.wvalu, (cdouble_p)net.bias, in, a);
+            cdouble_p wv = (cdouble_p)net.wvalu + NB * DIN * 8;
+#pragma unroll 1
+            for (int l = 1; l < NH; ++l) {
+                double o[H];
+                dense_tansig<H, H>(wv, (cdouble_p)net.bias + l * 64, a, o);
+#pragma unroll
+                for (int j = 0; j < H; ++j) a[j] = o[j];
+                wv += NB * H * 8;
+            }
+            cdouble_p wout = (cdouble_p)net.wout;
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int j = 0; j + 1 < H; j += 2) {
+                p0 = fma(a[j], wout[j], p0);
+                p1 = fma(a[j + 1], wout[j + 1], p1);
+            }
+            if (H & 1) p0 = fma(a[H - 1], wout[H - 1], p0);
+            {
+#pragma clang fp contract(off)
+                double acc = p0 + p1;
+                acc = acc + net.b_out;
+                const double y = (acc - net.y_ymin) / net.y_gain + net.y_xoffset;
+                obj = cd.negSM;
+                obj = obj + y * cd.max_elem;
+            }
+        }
+        if (valid) {
+            if (A.flags & SDPCUT_EIG) A.eig_out[out_idx] = lam;
+            if (A.flags & SDPCUT_NN) A.obj_out[out_idx] = obj;
+        }
     }
 }
 
@@ -510,7 +672,14 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags)
     } else {
         mfma_ok = true;   // eig only: the network part of the kernel is skipped
     }
-    if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
+    if (h->kernel_variant == SDPCUT_KERNEL_VALU && mfma_ok) {
+        const int64_t ntiles = (b.n + 255) / 256;
+        const int grid = grid_for(h, ntiles, 8);
+        if (K == 2) hipLaunchKernelGGL((score_valu_kernel<2, 64, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 3) hipLaunchKernelGGL((score_valu_kernel<3, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 4) hipLaunchKernelGGL((score_valu_kernel<4, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 5) hipLaunchKernelGGL((score_valu_kernel<5, 64, 4>), dim3(grid), dim3(256), 0, h->stream, A);
+    } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         const int grid = grid_for(h, ntiles, 8);
         if (K == 2) hipLaunchKernelGGL((score_mfma_kernel<2, 64, 3>), dim3(grid), dim3(256), 0, h->stream, A);

@@ -59,26 +59,25 @@ class RankList(Sequence):
     ``a + b`` (cut_select_qcqp.py:79) and slicing return plain lists of entries.
     """
 
-    def __init__(self, owner, binding, kind, total, vars_values, head_idx, head_score):
+    def __init__(self, owner, binding, kind, total, vars_values, head_idx, head_score, strat=None, sel_size=0):
         self._owner, self._b, self._kind, self._n = owner, binding, kind, int(total)
         self._vv = vars_values
-        self._idx = np.full(self._n, -1, dtype=np.int64)
-        self._score = np.empty(self._n)
-        h = head_idx.shape[0]
-        self._idx[:h], self._score[:h] = head_idx, head_score
-        self._have = h
-        self._serial = binding.rank_serial
+        self._strat, self._sel_size = strat, sel_size
+        self._idx, self._score = head_idx, head_score
+        self._have = head_idx.shape[0]
+        self._point = binding.point_token
 
     # -- data access -----------------------------------------------------------------
     def _need(self, upto):
+        """The head came from the device's top-k selection; anything beyond it asks for the
+        complete ranking (full device sort), once."""
         upto = min(upto, self._n)
         if upto <= self._have:
             return
-        if self._b.rank_serial != self._serial:
-            raise RuntimeError("rank list is stale: the device ranking has been replaced by a newer call")
-        idx, sc = self._b.scorer.rank_fetch(self._have, upto - self._have)
-        self._idx[self._have:upto], self._score[self._have:upto] = idx, sc
-        self._have = upto
+        if self._b.point_token != self._point:
+            raise RuntimeError("rank list is stale: the device now holds the scores of a newer LP point")
+        idx, sc, total, _, _ = self._b.scorer.rank(self._strat, self._sel_size, max_out=self._n)
+        self._idx, self._score, self._have = idx, sc, idx.shape[0]
 
     def ids(self, count=None):
         count = self._n if count is None else min(count, self._n)
@@ -246,10 +245,12 @@ class GpuCutSelectionMixin(object):
         if N == 0:
             return []       # strat 4 included: sel_size is clamped to 0 and the reference falls through
         vv = self._gpu_point(b, vars_values, flags)
-        head = min(N, max(sel_size, _HEAD))
+        # head fetched eagerly: what the loop can consume (sel_size is only passed for strat 4;
+        # for 1 / 2 the cap of :37 bounds it).  Heads <= 8192 take the device's top-k select path.
+        head = min(N, sel_size if (strat == 4 and sel_size > 0) else _HEAD)
         idx, score, total, new_strat, counters = b.scorer.rank(strat, sel_size, head)
         b.rank_serial += 1
-        rl = RankList(self, b, 1 if strat == 1 else 2, total, vv, idx, score)
+        rl = RankList(self, b, 1 if strat == 1 else 2, total, vv, idx, score, strat=strat, sel_size=sel_size)
         rl.counters = counters
         if strat == 4:
             # the reference divides by sel_size and swallows the ZeroDivisionError, falling

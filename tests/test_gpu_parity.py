@@ -102,12 +102,12 @@ def test_get_eigendecomp_twin(lib, oracle):
 
 # --------------------------------------------------------------------------- scoring
 @pytest.mark.parametrize("k", [2, 3, 4, 5])
-@pytest.mark.parametrize("kernel", ["mfma", "simple"])
+@pytest.mark.parametrize("kernel", ["mfma", "simple", "valu"])
 def test_scores_vs_oracle_synthetic(lib, scorer, oracle, k, kernel):
     from sdpcutsel_via_nn_amd import _capi, synthetic
     wl = synthetic.make_workload(nb_vars=100, k=k, count=20011, seed=7 + k)
     n, L = 100, 5050
-    scorer.set_option(_capi.OPT_KERNEL, _capi.KERNEL_MFMA if kernel == "mfma" else _capi.KERNEL_SIMPLE)
+    scorer.set_option(_capi.OPT_KERNEL, {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[kernel])
     try:
         scorer.set_instance(n, wl["Q_arr"])
         scorer.set_candidates(wl["set_inds"], wl["ks"])
@@ -466,3 +466,66 @@ def test_sharded_selector_sparse_strong_regime(scorer, oracle):
             assert r["counters"]["strong"] == cnt["strong"] and r["counters"]["violated"] == cnt["violated"]
     finally:
         scorer.set_stream(None)
+
+
+# --------------------------------------------------------------------------- top-k select path
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_topk_select_path_equals_full_sort_full_size(full_c2, scorer, strat):
+    """Heads of <= 8192 entries come from the radix-select path (topk.hip); they must equal the
+    head of the full stable sort bit for bit -- with ~6 exact duplicates of every candidate, the
+    k-th entry almost always sits inside a group of equal keys."""
+    wl, eig, obj = full_c2
+    sel = 5000
+    full = scorer.rank(strat, sel, max_out=10 ** 6)
+    for k in (1, 2, 63, 64, 65, 1000, 4999, 5000):
+        ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=k)
+        assert np.array_equal(ids, full[0][:k]), (strat, k)
+        assert np.array_equal(score, full[1][:k])
+        assert total == full[2] and new_strat == full[3]
+        assert cnt["nb_violated"] == full[4]["nb_violated"]
+        if strat == 4:
+            assert cnt["strong"] == full[4]["strong"] and cnt["violated"] == full[4]["violated"]
+    if strat != 4:
+        for k in (8191, 8192):
+            ids, score, _, _, _ = scorer.rank(strat, sel, max_out=k)
+            assert np.array_equal(ids, full[0][:k]) and np.array_equal(score, full[1][:k])
+
+
+@pytest.mark.parametrize("tag", ["spar020_100_1_d4", "spar040_030_1_d5"])
+@pytest.mark.parametrize("point", ["mck", "rnd", "psd"])
+def test_topk_select_path_on_tie_heavy_instances(scorer, golden_boxqp, tag, point):
+    """Structured LP vertices: thousands of exactly equal scores, empty classes, k > class size."""
+    from sdpcutsel_via_nn_amd import _capi
+    g = golden_boxqp
+    _bind_golden(scorer, g, tag, point)
+    N = g[tag + "_set_inds"].shape[0]
+    scorer.score(_capi.EIG | _capi.NN)
+    for strat in (1, 2, 4, _capi.PART_STRONG):
+        for sel in (1, 7, max(1, N // 10), min(N, 8192)):
+            full = scorer.rank(strat, sel, max_out=10 ** 6)
+            for k in sorted({1, sel, min(N, 8192)}):
+                if strat == 4 and k > sel:
+                    continue
+                ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=k)
+                assert np.array_equal(ids, full[0][:k]), (strat, sel, k)
+                assert np.array_equal(score, full[1][:k])
+                assert total == full[2] and new_strat == full[3]
+
+
+def test_rank_list_tail_comes_from_full_sort(lib, golden_boxqp):
+    """The lazy RankList serves its head from the select path and the tail from one full sort."""
+    g, tag = golden_boxqp, "spar020_100_1_d4"
+    n = int(g[tag + "_nb_vars"])
+    sets = [[int(v) for v in g[tag + "_set_inds"][i, :g[tag + "_k"][i]]] for i in range(g[tag + "_k"].shape[0])]
+    pos = [[n * s[a] - s[a] * (s[a] + 1) // 2 + s[b] for a in range(len(s)) for b in range(a, len(s))] for s in sets]
+    agg = [(s, p, None, None) for s, p in zip(sets, pos)]
+    cs = lib.CutSolver()
+    cs.set_instance(n, g[tag + "_Q_arr"], agg, dim=4)
+    vv = g[tag + "_rnd_vars"]
+    new_strat, rl = cs._sel_eigcut_by_ordering_on_measure(4, vv, 1, sel_size=410)
+    assert rl._have == 410 and len(rl) == len(agg)
+    assert [e[0] for e in rl[0:410]] == g[tag + "_rnd_s4_order"][:410].tolist()
+    assert rl[len(agg) - 1][0] == int(g[tag + "_rnd_s4_order"][-1])          # forces the full ranking
+    assert [e[0] for e in rl] == g[tag + "_rnd_s4_order"].tolist()
+    rl2 = cs._sel_eigcut_by_ordering_on_measure(2, vv, 1)
+    assert [e[0] for e in rl2] == g[tag + "_rnd_s2_order"].tolist()

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Kernel-time breakdown on the GPU box: score kernel per variant and flag set (hipEvents inside
+the library), config-2 workload.  Usage: python tools/ablate.py [k] [count]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sdpcutsel_via_nn_amd import _capi, networks, synthetic  # noqa: E402
+
+
+def main():
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 6
+    wl = synthetic.make_workload(nb_vars=100, k=k, count=count, seed=7)
+    sc = _capi.Scorer(0)
+    sc.set_option(_capi.OPT_TIMING, 1)
+    sc.set_network(k, *networks.load_network(k))
+    sc.set_instance(100, wl["Q_arr"])
+    sc.set_candidates(wl["set_inds"], wl["ks"])
+    sc.set_point(wl["vars_values"])
+    for name, kv in (("mfma", _capi.KERNEL_MFMA), ("valu", _capi.KERNEL_VALU), ("simple", _capi.KERNEL_SIMPLE)):
+        sc.set_option(_capi.OPT_KERNEL, kv)
+        for fname, flags in (("eig", _capi.EIG), ("nn", _capi.NN), ("eig+nn", _capi.EIG | _capi.NN)):
+            ts = []
+            for it in range(8):
+                sc.score(flags)
+                ts.append(sc.last_timing()[0])
+            print("k=%d N=%d %-6s %-6s  median %.1f us  min %.1f us" % (k, count, name, fname, 1e3 * np.median(ts[2:]),
+                                                                      1e3 * min(ts[2:])), flush=True)
+    sc.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,5 +10,5 @@ tail -5 gpurun_out/test_$tag.log
 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || { tail -20 gpurun_out/bench_$tag.err; exit 1; }
 cat gpurun_out/bench_$tag.json
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o prof -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_prof_$tag.json 2> gpurun_out/prof_$tag.err || { tail -20 gpurun_out/prof_$tag.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o prof -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_prof_$tag.json 2> gpurun_out/prof_$tag.err || { tail -20 gpurun_out/prof_$tag.err; exit 1; }
 find gpurun_out/prof_$tag -name "*stats*" | head
