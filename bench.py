@@ -104,11 +104,15 @@ def main():
 
     def step():
         sc.set_point_device(d_vars.data_ptr())
-        sc.score(_capi.EIG | _capi.NN)
-        res = sel.select(4, SEL)
-        ids = res["ids"].cpu().numpy()
-        mine = ids[(ids >= lo) & (ids < hi)] - lo
-        rows = sc.cut_rows(mine)
+        if world == 1:
+            # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> one D2H
+            res = rows = sc.select_round(4, SEL)
+        else:
+            sc.score(_capi.EIG | _capi.NN)
+            res = sel.select(4, SEL)                     # per-shard heads, RCCL all-gather, replicated merge
+            ids = res["ids"].cpu().numpy()
+            mine = ids[(ids >= lo) & (ids < hi)] - lo
+            rows = sc.cut_rows(mine)                     # each rank generates the rows of its own candidates
         kernel_ms.append(sc.last_timing()[0])
         return res, rows
 

@@ -167,6 +167,23 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
                     double *coef, double *rhs, int64_t *cols, int32_t *ks);
 
 /*
+ * One selection round in one call: what the loop body does between two LP solves
+ * (cut_select_qp.py:165-182: _sel_eigcut_by_ordering_on_measure followed by
+ * _gen_eigcuts_selected).  Scores with the flags the strategy needs (unless already scored
+ * at this point), ranks, and produces the eigen-cut rows of the first min(sel_size, length)
+ * entries; a single device-to-host transfer returns everything.  Outputs are sized for
+ * sel_size entries; *n_out entries are written.  idx_out are GLOBAL candidate indices;
+ * the column indices of row c follow from its index set (see sdpcut_cut_rows) and are not
+ * transferred.  lam_min / coef / rhs / ks as in sdpcut_cut_rows, except that coef rows have
+ * the caller's stride coef_ld (>= k + k(k+1)/2 of the largest candidate, <= SDPCUT_ROW_LD):
+ * a 3-variable-only list moves 9 instead of 20 doubles per row over PCIe.
+ */
+int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld,
+                        int64_t *idx_out, double *score_out, double *lam_min, double *coef,
+                        double *rhs, int32_t *ks, int64_t *n_out, int64_t *n_total,
+                        int32_t *new_strat, int64_t *counters);
+
+/*
  * Batched twin of _get_eigendecomp (cut_select_qp.py:788-797) for explicit sub-matrices:
  * x_rho [count][k], X_rho [count][k(k+1)/2] (upper triangle, row-major).  Writes ascending
  * eigenvalues [count][k+1] and, if evecs != NULL, eigenvectors [count][k+1][k+1] with

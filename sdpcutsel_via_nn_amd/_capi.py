@@ -48,6 +48,7 @@ SIGNATURES = {
     "sdpcut_merge_topk_device": [_vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _vp, _vp],
     "sdpcut_gather_scores_device": [_vp, _c.c_int64, _vp, _vp, _vp],
     "sdpcut_cut_rows": [_vp, _c.c_int64, _i64p, _dp, _dp, _dp, _i64p, _i32p],
+    "sdpcut_select_round": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _i64p, _dp, _dp, _dp, _dp, _i32p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
@@ -161,6 +162,8 @@ class Scorer(object):
                                                     set_inds.shape[1], _ptr(ks, _i32p), int(global_base)))
         self.N = int(set_inds.shape[0])
         self.base = int(global_base)
+        kmax = int(ks.max()) if ks.size else 2
+        self.row_len = kmax * (kmax + 3) // 2
 
     def set_point(self, vars_values):
         vv = _f64(vars_values)
@@ -233,6 +236,29 @@ class Scorer(object):
         self._check(self._lib.sdpcut_cut_rows(self._h, c, _ptr(idx, _i64p), _ptr(lam, _dp), _ptr(coef, _dp),
                                               _ptr(rhs, _dp), _ptr(cols, _i64p), _ptr(ks, _i32p)))
         return lam, coef, rhs, cols, ks
+
+    def select_round(self, strat, sel_size):
+        """score (if needed) + rank + cut rows of the head in one call
+        -> dict(idx, score, lam, coef, rhs, ks, n_total, new_strat, counters)."""
+        cap = max(0, min(int(sel_size), self.N))
+        m = max(cap, 1)
+        ld = self.row_len
+        if getattr(self, "_round_cap", (0, 0)) != (m, ld):     # reuse the output buffers across rounds
+            self._round_bufs = (np.empty(m, dtype=np.int64), np.empty(m), np.empty(m), np.empty((m, ld)),
+                                np.empty(m), np.empty(m, dtype=np.int32))
+            self._round_cap = (m, ld)
+        idx, sc, lam, coef, rhs, ks = self._round_bufs
+        n_out, n_total, new_strat = _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
+        cnt = np.zeros(4, dtype=np.int64)
+        self._check(self._lib.sdpcut_select_round(
+            self._h, int(strat), int(sel_size), ld, _ptr(idx, _i64p), _ptr(sc, _dp), _ptr(lam, _dp), _ptr(coef, _dp),
+            _ptr(rhs, _dp), _ptr(ks, _i32p), ctypes.byref(n_out), ctypes.byref(n_total), ctypes.byref(new_strat),
+            _ptr(cnt, _i64p)))
+        w = n_out.value
+        return dict(idx=idx[:w], score=sc[:w], lam=lam[:w], coef=coef[:w], rhs=rhs[:w], ks=ks[:w],
+                    n_total=int(n_total.value), new_strat=int(new_strat.value),
+                    counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]),
+                                  nb_positive=int(cnt[3])))
 
     def eig_batch(self, k, x_rho, X_rho, want_vectors=False):
         x_rho, X_rho = _f64(x_rho), _f64(X_rho)

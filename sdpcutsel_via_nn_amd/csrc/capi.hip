@@ -79,6 +79,7 @@ int sdpcut_destroy(sdpcut_handle h)
     free_candidates(h);
     free_rank_ws(h);
     free_topk_ws(h);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -196,6 +197,17 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
             fan = H;
         }
     }
+    // rows 48..51 of every hidden layer, for the VALU tail of the MFMA kernel: [layer][4][64]
+    const size_t o_wtail = reserve((size_t)nh * 4 * 64);
+    {
+        int fan = d_in;
+        for (int l = 0; l < nh; ++l) {
+            for (int u = 0; u < 4; ++u)
+                for (int i = 0; i < fan; ++i)
+                    if (48 + u < H) blob[o_wtail + ((size_t)l * 4 + u) * 64 + i] = W[l][(size_t)(48 + u) * fan + i];
+            fan = H;
+        }
+    }
     // scalar-operand packing of the VALU kernel: [layer][j/8][i][j%8]
     const int NBv = (H + 7) / 8;
     // (+16: the kernel streams the weights in 16-double batches and may read past an odd fan-in)
@@ -228,6 +240,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
     d.wout = nh_.d_blob + o_wout;
     d.wfrag = nh_.d_blob + o_frag;
     d.wvalu = nh_.d_blob + o_wvalu;
+    d.wtail = nh_.d_blob + o_wtail;
     for (int l = 0; l < n_layers; ++l) { d.raw_w[l] = nh_.d_blob + o_rw[l]; d.raw_b[l] = nh_.d_blob + o_rb[l]; }
     d.ymin = ymin; d.b_out = B[nh][0]; d.y_ymin = y_ymin; d.y_gain = y_gain; d.y_xoffset = y_xoffset;
     nh_.set = true;
@@ -307,6 +320,9 @@ int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, i
         HIP_TRY(h, hipMemcpy(b.d_orig, orig[k].data(), orig[k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     h->N = N;
+    h->row_len_max = 5;
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k)
+        if (cnt[k]) h->row_len_max = k * (k + 3) / 2;
     int rc = ensure_rank_ws(h, N);
     if (rc) return rc;
     return SDPCUT_OK;
@@ -499,7 +515,7 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
     int64_t *d_cols = (int64_t *)p; p += c * 8 * SDPCUT_ROW_LD;
     int32_t *d_ks = (int32_t *)p;
     HIP_TRY(h, hipMemcpyAsync(d_idx, idx, c * 8, hipMemcpyHostToDevice, h->stream));
-    rc = launch_cut_rows(h, count, d_idx, d_lam, d_coef, d_rhs, d_cols, d_ks);
+    rc = launch_cut_rows(h, count, nullptr, d_idx, 0, d_lam, d_coef, SDPCUT_ROW_LD, d_rhs, d_cols, d_ks);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(lam_min, d_lam, c * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(rhs, d_rhs, c * 8, hipMemcpyDeviceToHost, h->stream));
@@ -507,6 +523,92 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
     HIP_TRY(h, hipMemcpyAsync(cols, d_cols, c * 8 * SDPCUT_ROW_LD, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(ks, d_ks, c * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, int64_t *idx_out,
+                        double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks, int64_t *n_out,
+                        int64_t *n_total, int32_t *new_strat, int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_STRAT_COMB)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "strategy must be 1 (feasibility), 2 (optimality) or 4 (combined)");
+    if (sel_size < 0 || (sel_size > 0 && (!idx_out || !score_out || !lam_min || !coef || !rhs || !ks)) || !n_out)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    if (!h->have_point || !h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
+    if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "coef_ld must hold the longest row (k + k(k+1)/2) and be <= SDPCUT_ROW_LD");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
+                          : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
+    int rc;
+    if ((h->scored & need) != need) {
+        rc = sdpcut_score(h, need & ~h->scored);
+        if (rc) return rc;
+    }
+    int64_t cap = sel_size < h->N ? sel_size : h->N;
+    *n_out = 0;
+    if (cap == 0)   // nothing to generate; still report the ranking's length / strategy switch
+        return sdpcut_rank(h, strat, sel_size, 0, nullptr, nullptr, n_total, new_strat, counters);
+    // one device block, returned by ONE transfer: counters | idx | score | lam | rhs | coef | ks
+    const size_t c = (size_t)cap;
+    const size_t ret_bytes = 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4;
+    rc = ensure_stage(h, ret_bytes + 64);
+    if (rc) return rc;
+    if (h->pinned_bytes < ret_bytes) {
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        h->pinned = nullptr;
+        h->pinned_bytes = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pinned, ret_bytes, hipHostMallocDefault));
+        h->pinned_bytes = ret_bytes;
+    }
+    char *p = (char *)h->d_stage;
+    int64_t *d_c4 = (int64_t *)p; p += 64;
+    int64_t *d_idx = (int64_t *)p; p += c * 8;
+    double *d_sc = (double *)p; p += c * 8;
+    double *d_lam = (double *)p; p += c * 8;
+    double *d_rhs = (double *)p; p += c * 8;
+    double *d_coef = (double *)p; p += c * 8 * (size_t)coef_ld;
+    int32_t *d_ks = (int32_t *)p;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    int64_t w = 0;
+    bool have = false;
+    // fast path: selection, rows and the transfer are enqueued back to back, one synchronisation
+    const int64_t *d_cnt = nullptr;
+    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        HIP_TRY(h, hipMemcpyAsync(d_c4, d_cnt, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+        rc = launch_cut_rows(h, cap, d_cnt + 3, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
+    }
+    if (!have) {
+        // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
+        rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters);
+        if (rc) return rc;
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        if (w > 0) {
+            rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    if (w > 0) {
+        const char *q = (const char *)h->pinned + 64;
+        const size_t ww = (size_t)w;
+        std::memcpy(idx_out, q, ww * 8); q += c * 8;
+        std::memcpy(score_out, q, ww * 8); q += c * 8;
+        std::memcpy(lam_min, q, ww * 8); q += c * 8;
+        std::memcpy(rhs, q, ww * 8); q += c * 8;
+        std::memcpy(coef, q, ww * 8 * (size_t)coef_ld); q += c * 8 * (size_t)coef_ld;
+        std::memcpy(ks, q, ww * 4);
+    }
+    *n_out = w;
     return SDPCUT_OK;
 }
 

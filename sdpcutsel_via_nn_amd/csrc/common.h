@@ -20,6 +20,7 @@ struct NetDev {
     int width;             // hidden width (all hidden layers equal: 64 or 50)
     int s0, sh;            // k-steps (of 4) of the first / the other hidden layers
     const double *wfrag;   // MFMA A-fragments: layer-major, then [t][s][lane]
+    const double *wtail;   // [layer][4][64]: rows 48..51 of each hidden layer (VALU tail of the MFMA kernel)
     const double *wvalu;   // scalar-operand packing: layer-major, then [j/8][i][j%8], zero padded
     const double *bias;    // [n_hidden][64] zero padded
     const double *wout;    // [64] zero padded output weights
@@ -58,6 +59,7 @@ struct sdpcut_ctx {
     bool have_point = false;
 
     int64_t N = 0, base = 0;
+    int32_t row_len_max = 5;       // k + k(k+1)/2 of the largest candidate size present
     Bucket bucket[SDPCUT_MAX_K + 1];
     int32_t *d_set_orig = nullptr; // [N][5] padded, caller order
     int32_t *d_k = nullptr;        // [N]
@@ -82,6 +84,8 @@ struct sdpcut_ctx {
     // small staging
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    void *pinned = nullptr;        // host staging of sdpcut_select_round (one D2H per round)
+    size_t pinned_bytes = 0;
 };
 
 int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
@@ -96,8 +100,8 @@ int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
 
 // score.hip
 int launch_score(sdpcut_ctx *h, uint32_t flags);
-int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_idx, double *d_lam, double *d_coef,
-                    double *d_rhs, int64_t *d_cols, int32_t *d_ks);
+int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
+                    double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks);
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
                      double *d_vals, double *d_vecs);
 int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);
@@ -114,7 +118,14 @@ int gather_scores_on_device(sdpcut_ctx *h, int64_t count, const int64_t *d_ids, 
 int rank_fetch_on_device(sdpcut_ctx *h, int64_t offset, int64_t count, int64_t *d_idx_out, double *d_score_out);
 void free_rank_ws(sdpcut_ctx *h);
 
+int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
+                      double *d_score_out, const int64_t **d_c4);
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[4],
+                     int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out);
+
 // topk.hip
+int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
+                        double *d_score_out, const int64_t **d_counters_out);
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[4]);
 void free_topk_ws(sdpcut_ctx *h);

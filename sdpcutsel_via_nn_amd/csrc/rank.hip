@@ -167,6 +167,60 @@ int ensure_rank_ws(sdpcut_ctx *h, int64_t n)
 
 static inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
 
+// Fast path of the ranking: the caller wants only a short head (the loop consumes <= 5000
+// entries, _SDP_CUTS_PER_ROUND_MAX): radix select + small sort instead of sorting all N.
+// Returns 1 if the selection has been enqueued (no host synchronisation), 0 if the request is
+// not eligible, < 0 on error.  *d_c4 = device address of {class size, nb_violated, nb_positive, k_eff}.
+int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
+                      double *d_score_out, const int64_t **d_c4)
+{
+    const int64_t n = h->N;
+    if (sel_size > n) sel_size = n;
+    if (!(n > 0 && max_out >= 1 && max_out <= 8192)) return 0;
+    int mode = 0;
+    double add = 0.0;
+    if (strat == SDPCUT_STRAT_FEAS) mode = 1;
+    else if (strat == SDPCUT_STRAT_OPT) mode = 2;
+    else if (strat == SDPCUT_PART_STRONG) mode = 3;
+    else if (strat == SDPCUT_STRAT_COMB && sel_size >= 1 && max_out <= sel_size) {
+        // combined scan, common regime: at least sel_size candidates are positive AND violated.
+        // The scan stops after sel_size of them; the re-sorted list starts with exactly those,
+        // +BIG_M, in obj_improve order (cut_select_qp.py:606-625).  rank_fast_finish verifies
+        // the regime through the class size.
+        mode = 3;
+        add = SDPCUT_BIG_M;
+    }
+    if (!mode) return 0;
+    int rc = topk_select_enqueue(h, mode, max_out, add, d_idx_out, d_score_out, d_c4);
+    return rc ? rc : 1;
+}
+
+// Host side of the fast path once the four counters are on the host.  Returns 1 if the enqueued
+// selection is the answer, 0 if the general path has to run (combined scan visiting everything).
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[4],
+                     int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out)
+{
+    const int64_t n = h->N;
+    if (sel_size > n) sel_size = n;
+    const bool comb = strat == SDPCUT_STRAT_COMB;
+    if (comb && c4[0] < sel_size) return 0;
+    const int64_t total = (strat == SDPCUT_STRAT_OPT || comb) ? n : c4[0];
+    const int64_t w = total < max_out ? total : max_out;
+    h->last_total = -1;                     // only the head exists: nothing to fetch later
+    if (n_written) *n_written = w;
+    if (n_total) *n_total = total;
+    int64_t cnt[4] = {c4[1], 0, 0, c4[2]};
+    if (strat == SDPCUT_STRAT_FEAS || strat == SDPCUT_PART_STRONG) cnt[0] = c4[0];
+    if (comb) { cnt[1] = sel_size; cnt[2] = sel_size; }
+    if (new_strat) {
+        *new_strat = strat;
+        if (comb && (double)cnt[1] / (double)sel_size < (double)cnt[2] / (double)n) *new_strat = SDPCUT_STRAT_FEAS;
+    }
+    if (counters_out)
+        for (int i = 0; i < 4; ++i) counters_out[i] = cnt[i];
+    return 1;
+}
+
 int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
                    double *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
                    int64_t *counters_out)
@@ -177,46 +231,17 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     if (sel_size > n) sel_size = n;                 // cut_select_qp.py:551
     if (sel_size < 0) sel_size = 0;
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // ---- fast path: the caller wants only a short head (the loop consumes <= 5000 entries,
-    // _SDP_CUTS_PER_ROUND_MAX): radix select + small sort instead of sorting all N (topk.hip)
-    if (n > 0 && max_out >= 1 && max_out <= 8192) {
-        int mode = 0;
-        int64_t k = max_out;
-        double add = 0.0;
-        if (strat == SDPCUT_STRAT_FEAS) mode = 1;
-        else if (strat == SDPCUT_STRAT_OPT) mode = 2;
-        else if (strat == SDPCUT_PART_STRONG) mode = 3;
-        else if (strat == SDPCUT_STRAT_COMB && sel_size >= 1 && max_out <= sel_size) {
-            // combined scan, common regime: at least sel_size candidates are positive AND violated.
-            // The scan stops after sel_size of them; the re-sorted list starts with exactly those,
-            // +BIG_M, in obj_improve order (cut_select_qp.py:606-625).  Verified below via the class size.
-            mode = 3;
-            add = SDPCUT_BIG_M;
-        }
-        if (mode) {
+    // ---- fast path: the caller wants only a short head (topk.hip)
+    {
+        const int64_t *d_c4 = nullptr;
+        rc = rank_fast_enqueue(h, strat, sel_size, max_out, d_idx_out, d_score_out, &d_c4);
+        if (rc < 0) return rc;
+        if (rc == 1) {
             int64_t c4[4] = {0, 0, 0, 0};
-            rc = topk_select_on_device(h, mode, k, add, d_idx_out, d_score_out, c4);
-            if (rc) return rc;
-            const bool comb = strat == SDPCUT_STRAT_COMB;
-            if (!comb || c4[0] >= sel_size) {
-                const int64_t total = (strat == SDPCUT_STRAT_OPT || comb) ? n : c4[0];
-                const int64_t w = total < max_out ? total : max_out;
-                h->last_total = -1;                     // only the head exists: nothing to fetch later
-                if (n_written) *n_written = w;
-                if (n_total) *n_total = total;
-                cnt[0] = c4[1]; cnt[3] = c4[2];
-                if (strat == SDPCUT_STRAT_FEAS || strat == SDPCUT_PART_STRONG) cnt[0] = (strat == SDPCUT_STRAT_FEAS) ? c4[0] : c4[0];
-                if (comb) { cnt[1] = sel_size; cnt[2] = sel_size; }
-                if (new_strat) {
-                    *new_strat = strat;
-                    if (comb && (double)cnt[1] / (double)sel_size < (double)cnt[2] / (double)n) *new_strat = SDPCUT_STRAT_FEAS;
-                }
-                if (counters_out)
-                    for (int i = 0; i < 4; ++i) counters_out[i] = cnt[i];
-                return 0;
-            }
+            HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (rank_fast_finish(h, strat, sel_size, max_out, c4, n_written, n_total, new_strat, counters_out)) return 0;
             // fewer strong candidates than sel_size: every entry is visited -> general path below
-            for (int i = 0; i < 8; ++i) cnt[i] = 0;
         }
     }
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 8 * sizeof(int64_t), h->stream));

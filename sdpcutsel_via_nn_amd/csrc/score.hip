@@ -111,25 +111,21 @@ __device__ __forceinline__ double tansig_lib(double n)
     return 2.0 / (exp(-2.0 * n) + 1.0) - 1.0;
 }
 
-// The same formula with a branch-free exp and reciprocal (29 fp64 instructions instead of the
-// ~36 of the library route; profiles/r01_ubench_fp64_rates.txt).  y = -2n is clamped to
-// [-80, 80], where 2/(1+e^y)-1 has long saturated to -1 / +1 in fp64; exp(y) = 2^k * p(r) with
-// k = rint(y log2 e), r = y - k ln2 in two pieces (|r| <= 0.3466) and the degree-13 Taylor
-// polynomial (truncation 4e-18); the reciprocal is v_rcp_f64 (4.5e-8) + two Newton steps.
-// Absolute error vs the exact formula <= 4e-16, the same class as the library route.
+// The same formula with a branch-free exp and reciprocal: 25 VALU instructions instead of the
+// ~36 of the library route (every VALU instruction costs ~2-2.5 ns per wave on gfx950 whatever
+// its type, v_rcp_f64 ~7 ns: profiles/r01_ubench_fp64_instruction_costs.txt -- the COUNT is
+// what matters).  With y = -2n:  exp(y) = 2^k * exp(r/8)^8,  k = rint(y log2 e),  r/8 = y/8 -
+// k ln2/8 in two pieces (|r/8| <= 0.0433), degree-8 Taylor polynomial (truncation 2e-18), three
+// squarings; only the upper clamp is needed (y <= 704 keeps exp finite; towards -inf ldexp
+// underflows to 0 and the result saturates at +1 by itself).  The reciprocal is v_rcp_f64
+// (4.5e-8) + one cubically convergent step.  Absolute error vs the exact formula <= 1e-15.
 __device__ __forceinline__ double tansig(double n)
 {
-    double y = -2.0 * n;
-    y = fmin(fmax(y, -80.0), 80.0);
-    const double k = rint(y * 1.4426950408889634074);
-    double r = fma(k, -6.93147180369123816490e-01, y);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.60590438368216145994e-10;              // 1/13!
-    p = fma(p, r, 2.08767569878680989792e-09);          // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);          // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);          // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);          // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);          // 1/8!
+    const double y8 = fmin(n * -0.25, 88.0);
+    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
+    double r = fma(k, -8.66433975461404770613e-02, y8);              // ln2_hi / 8
+    r = fma(k, -2.38526866158823462503e-11, r);                      // ln2_lo / 8
+    double p = 2.48015873015873015873e-05;              // 1/8!
     p = fma(p, r, 1.98412698412698412698e-04);          // 1/7!
     p = fma(p, r, 1.38888888888888888889e-03);          // 1/6!
     p = fma(p, r, 8.33333333333333333333e-03);          // 1/5!
@@ -138,11 +134,46 @@ __device__ __forceinline__ double tansig(double n)
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
+    p = p * p;
+    p = p * p;
+    p = p * p;
     const double d = ldexp(p, (int)k) + 1.0;
     double q = __builtin_amdgcn_rcp(d);
-    q = fma(fma(-d, q, 1.0), q, q);
-    q = fma(fma(-d, q, 1.0), q, q);
+    const double e = fma(-d, q, 1.0);
+    q = fma(q, fma(e, e, e), q);                        // q (1 + e + e^2)
     return fma(2.0, q, -1.0);
+}
+
+// The LDS strips of the MFMA kernel (feat, ynn) are private to one wave.  A wave's LDS
+// instructions are issued and serviced in program order, so a write followed by a read of
+// another lane's slot needs no workgroup barrier -- only that the compiler keeps the order and
+// that the data has returned (lgkmcnt) before use.  Dropping __syncthreads() decouples the four
+// waves of a workgroup: none waits for the slowest (PMC: SQ_WAIT_ANY 45 % of wave cycles).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Tail rows of a hidden layer on the VALU: ts[u] holds this lane's partial dot product of tail
+// neuron u over the k-slots it owns (n = 4 s + q); the four k-slot lanes of a candidate column
+// (lane, lane^16, lane^32, lane^48) are summed, and lane q keeps neuron u = q in register 0 of
+// the last row tile -- exactly where the MFMA C/D layout would have put it.
+template <int NT>
+__device__ __forceinline__ d4 tail_rows(const double (&ts)[NT ? NT : 1], const double *bias, int q)
+{
+    double pre = 0.0;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        double v = ts[u];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        pre = (q == u) ? v + bias[u] : pre;
+    }
+    d4 out = {0.0, 0.0, 0.0, 0.0};
+    out[0] = (q < NT) ? tansig(pre) : 0.0;
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -155,6 +186,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     constexpr int S0 = (DIN + 3) / 4;      // k-steps of the input layer
     constexpr int SH = (H + 3) / 4;        // k-steps of a hidden->hidden layer
     constexpr int T = (H + 15) / 16;       // 16-neuron row tiles
+    // A last tile with <= 4 live rows (H = 50: neurons 48, 49) would cost a full 16-row MFMA
+    // per k-step for 1/8 of the work: those rows run on the VALU instead (tail_rows below).
+    constexpr int NT = (H - 16 * (T - 1) <= 4) ? H - 16 * (T - 1) : 0;
+    constexpr int TM = NT ? T - 1 : T;     // row tiles computed with MFMA
     constexpr int J = 2;                   // 16-candidate column tiles per pass
     constexpr int NPASS = 64 / (16 * J);
     static_assert(T == 4, "hidden width must be in 49..64");
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             }
             feat[wave][i][lane] = xp;
         }
-        __syncthreads();
+        wave_lds_sync();
 
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
@@ -208,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             const double *wf = net.wfrag;
             // ---------------- input layer
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TM; ++t) {
                 d4 bias;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bias[r] = net.bias[16 * t + 4 * r + q];
@@ -228,6 +263,23 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (NT > 0) {
+                double ts[J][NT ? NT : 1];
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) ts[j][u] = 0.0;
+#pragma unroll
+                for (int s = 0; s < S0; ++s)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        const double w = net.wtail[u * 64 + 4 * s + q];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) ts[j][u] = fma(bin[s][j], w, ts[j][u]);
+                    }
+#pragma unroll
+                for (int j = 0; j < J; ++j) cur[T - 1][j] = tail_rows<NT>(ts[j], net.bias + 16 * (T - 1), q);
+            }
             wf += T * S0 * 64;
             // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
 #pragma unroll 1
@@ -236,8 +288,16 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 for (int t = 0; t < T; ++t)
 #pragma unroll
                     for (int j = 0; j < J; ++j) prev[t][j] = cur[t][j];
+                // The A-fragment stream of the layer is one contiguous sequence g = t*SH + s.  Left
+                // alone hipcc loads each fragment right before its two MFMAs and waits vmcnt(0)
+                // (an L2 round trip per 128 MFMA cycles, the dominant stall in the first PMC run):
+                // a ring of RD fragments keeps RD-1 loads in flight; the sched_barriers pin the order.
+                constexpr int RD = 4, NG = TM * SH;
+                double ring[RD];
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
+                for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = wf[g * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
                     d4 bias;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bias[r] = net.bias[l * 64 + 16 * t + 4 * r + q];
@@ -245,18 +305,38 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                     for (int j = 0; j < J; ++j) cur[t][j] = bias;
 #pragma unroll
                     for (int s = 0; s < SH; ++s) {
-                        const double a = wf[(t * SH + s) * 64 + lane];
+                        const int g = t * SH + s;
+                        if (g + RD - 1 < NG) ring[(g + RD - 1) % RD] = wf[(g + RD - 1) * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < J; ++j)
-                            cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, prev[s / 4][j][s % 4],
+                            cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[g % RD], prev[s / 4][j][s % 4],
                                                                              cur[t][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int j = 0; j < J; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
-                    __builtin_amdgcn_sched_barrier(0);   // keep the next tile's weight loads from piling up
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (NT > 0) {
+                    double ts[J][NT ? NT : 1];
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) ts[j][u] = 0.0;
+#pragma unroll
+                    for (int s = 0; s < SH; ++s)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) {
+                            const double w = net.wtail[(l * 4 + u) * 64 + 4 * s + q];
+#pragma unroll
+                            for (int j = 0; j < J; ++j) ts[j][u] = fma(prev[s / 4][j][s % 4], w, ts[j][u]);
+                        }
+#pragma unroll
+                    for (int j = 0; j < J; ++j) cur[T - 1][j] = tail_rows<NT>(ts[j], net.bias + l * 64 + 16 * (T - 1), q);
                 }
                 wf += T * SH * 64;
             }
@@ -275,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 if (q == 0) ynn[wave][32 * pass + 16 * j + c16] = part;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         {
             // neural_net_3D.m:60-62, 81-85: y = (a + b - ymin)/gain + xoffset;  then :582
 #pragma clang fp contract(off)
@@ -286,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             obj = obj + y * cd.max_elem;
             if (valid) A.obj_out[out_idx] = obj;
         }
-        __syncthreads();   // feat / ynn are rewritten by the next tile
+        wave_lds_sync();   // feat / ynn are rewritten by the next tile
     }
 }
 
@@ -563,18 +643,24 @@ __device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *var
     *lam_out = lam;
 }
 
-__global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64_t *idx, const int32_t *set5,
-                                                      const int32_t *ks, const double *vars, int32_t nv,
-                                                      int64_t L, double *lam, double *coef, double *rhs,
-                                                      int64_t *cols, int32_t *ks_out)
+// count may be an upper bound: if d_limit != NULL only min(count, *d_limit) rows exist (the
+// device-side length of a ranking that the host has not read yet).  coef rows have stride
+// coef_ld >= k + k(k+1)/2 of the largest candidate; cols (stride SDPCUT_ROW_LD) is optional.
+__global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64_t *d_limit, const int64_t *idx,
+                                                      int64_t idx_base, const int32_t *set5, const int32_t *ks,
+                                                      const double *vars, int32_t nv, int64_t L, double *lam,
+                                                      double *coef, int coef_ld, double *rhs, int64_t *cols,
+                                                      int32_t *ks_out)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (d_limit && *d_limit < count) count = *d_limit;
     if (i >= count) return;
-    const int64_t c = idx[i];
+    const int64_t c = idx[i] - idx_base;
     const int k = ks[c];
     const int32_t *s5 = set5 + c * 5;
-    double *co = coef + i * SDPCUT_ROW_LD;
-    int64_t *cl = cols + i * SDPCUT_ROW_LD;
+    double co[SDPCUT_ROW_LD];
+    int64_t cl[SDPCUT_ROW_LD];
+#pragma unroll
     for (int m = 0; m < SDPCUT_ROW_LD; ++m) { co[m] = 0.0; cl[m] = -1; }
     ks_out[i] = k;
     switch (k) {
@@ -582,6 +668,11 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
     case 3: cut_row_one<3>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
     case 4: cut_row_one<4>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
     default: cut_row_one<5>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    }
+#pragma unroll
+    for (int m = 0; m < SDPCUT_ROW_LD; ++m) {
+        if (m < coef_ld) coef[i * coef_ld + m] = co[m];
+        if (cols) cols[i * SDPCUT_ROW_LD + m] = cl[m];
     }
 }
 
@@ -705,13 +796,14 @@ int launch_score(sdpcut_ctx *h, uint32_t flags)
     return 0;
 }
 
-int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_idx, double *d_lam, double *d_coef,
-                    double *d_rhs, int64_t *d_cols, int32_t *d_ks)
+int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
+                    double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks)
 {
     if (count == 0) return 0;
     const int grid = (int)((count + 63) / 64);
-    hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_idx, h->d_set_orig, h->d_k,
-                       h->d_vars, h->nb_vars, h->L, d_lam, d_coef, d_rhs, d_cols, d_ks);
+    hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_limit, d_idx, idx_base,
+                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
+                       d_ks);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }

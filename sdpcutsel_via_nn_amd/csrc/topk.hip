@@ -3,11 +3,16 @@
 // The reference sorts all N candidates (cut_select_qp.py:601, :653) but its caller consumes
 // only the first sel_size <= 5000 (_SDP_CUTS_PER_ROUND_MAX, :37).  For such heads a full sort
 // is wasted HBM traffic: this file finds the k-th largest key with an MSD radix select (eight
-// 8-bit histogram passes over the u64 score images, candidates outside the class masked to
-// key 0), compacts the k selected (key, index) pairs -- all keys above the threshold plus the
-// lowest-index keys equal to it, exactly what a stable descending sort would keep -- and sorts
-// them by (key desc, index asc) with one workgroup in LDS.  No host round trip between passes:
-// every block re-derives the running prefix from the global histograms of the earlier passes.
+// 8-bit histogram passes over the u64 score images; candidates outside the class are masked
+// to key 0), compacts the k selected (key, index) pairs -- every key above the threshold plus
+// the lowest-index keys equal to it, exactly what a stable descending sort would keep -- and
+// orders them by (key desc, index asc) with a counting sort spread over the chip.
+//
+// No host round trip anywhere: the last workgroup to finish a histogram pass (ticket counter)
+// resolves that digit and publishes (prefix, need) for the next launch; the kernel boundary is
+// the release/acquire.  Histogram cells and counters are written with device-scope atomics
+// and read back by the resolving block with device-scope atomic loads (per-XCD L2s are not
+// coherent for plain loads inside a launch).
 #include "common.h"
 #include "keys.h"
 
@@ -17,54 +22,102 @@
 
 enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3 };
 
-struct TopkWs {
-    uint32_t hist[8][256];   // [digit 7..0 -> row 0..7][bin]
-    int64_t counters[4];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] unused
-    uint32_t gt_counter;
-    uint32_t pad;
-    uint32_t blk_eq[TK_MAXBLK];
-};
-
-struct Resolved {
+struct TkState {
     uint64_t prefix;   // digits resolved so far, in place
-    int64_t need;      // how many of the elements matching the prefix are still wanted
+    int64_t need;      // how many of the keys matching the prefix are still wanted (0: nothing)
 };
 
-// Re-derive (prefix, need) after `done` passes (digits 7, 6, ...).  All 256 threads call it.
-__device__ Resolved resolve_prefix(const TopkWs *ws, int done, int64_t k)
+struct TopkWs {
+    uint32_t hist[8][256];   // [pass 0..7 = digit 7..0][bin]
+    int64_t counters[4];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
+    TkState state[9];        // state[p]: after p digits
+    uint32_t done[8];        // ticket counters of the passes
+    uint32_t blk_eq[TK_MAXBLK];
+    uint32_t blk_gt[TK_MAXBLK];
+};
+
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
 {
-    __shared__ uint32_t suf[256];
-    __shared__ uint64_t s_prefix;
-    __shared__ int64_t s_need;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int64_t ld_i64(const int64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS histogram update with one round of wave aggregation: in the first passes nearly every
+// key of a wave falls into the same bin, and 64 same-address LDS atomics would serialise.
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool active)
+{
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t lead_bin = (uint32_t)__shfl((int)bin, leader);
+    const unsigned long long same = __ballot(active && bin == lead_bin);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lead_bin], (uint32_t)__popcll(same));
+    if (active && bin != lead_bin) atomicAdd(&hist[bin], 1u);
+}
+
+// Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].
+__device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
+{
+    __shared__ uint32_t suf[TK_THREADS];
     const int t = threadIdx.x;
-    int64_t need = k < ws->counters[0] ? k : ws->counters[0];
-    uint64_t prefix = 0;
-    for (int p = 0; p < done; ++p) {
-        // suffix sums S[t] = sum_{b >= t} hist[p][b]
-        __syncthreads();
-        suf[t] = ws->hist[p][t];
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t v = (t + off < 256) ? suf[t + off] : 0u;
-            __syncthreads();
-            suf[t] += v;
-            __syncthreads();
-        }
-        const int64_t here = suf[t], above = (t < 255) ? suf[t + 1] : 0;
-        if (here >= need && above < need) {     // exactly one bin satisfies this when need >= 1
-            s_prefix = prefix | ((uint64_t)t << (8 * (7 - p)));
-            s_need = need - above;
-        }
-        __syncthreads();
-        if (need >= 1) {
-            prefix = s_prefix;
-            need = s_need;
-        }
+    int64_t need;
+    uint64_t prefix;
+    if (p == 0) {
+        const int64_t cls = ld_i64(&ws->counters[0]);
+        need = k < cls ? k : cls;
+        prefix = 0;
+        if (t == 0) ws->counters[3] = need;      // k_eff for the later kernels
+    } else {
+        need = ws->state[p].need;                // written by the previous launch
+        prefix = ws->state[p].prefix;
     }
-    Resolved r;
-    r.prefix = prefix;
-    r.need = need;
-    return r;
+    suf[t] = ld_u32(&ws->hist[p][t]);
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {     // suffix sums S[t] = sum_{b >= t} hist[b]
+        const uint32_t v = (t + off < 256) ? suf[t + off] : 0u;
+        __syncthreads();
+        suf[t] += v;
+        __syncthreads();
+    }
+    const int64_t here = suf[t], above = (t < 255) ? suf[t + 1] : 0;
+    if (need >= 1) {
+        if (here >= need && above < need) {       // exactly one bin
+            ws->state[p + 1].prefix = prefix | ((uint64_t)t << (8 * (7 - p)));
+            ws->state[p + 1].need = need - above;
+        }
+    } else if (t == 0) {
+        ws->state[p + 1].prefix = 0;
+        ws->state[p + 1].need = 0;
+    }
+}
+
+// publish this block's LDS histogram; the last block to arrive resolves the digit.
+// Hand-off per the CDNA4 guideline: every wave drains its atomics (vmcnt(0)), workgroup barrier,
+// ONE lane does the agent-scope release and takes the ticket (a __threadfence() by all 256
+// threads of all 512 blocks cost ~30 us per pass); the last block acquires once.
+__device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist)
+{
+    __shared__ uint32_t ticket;
+    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][threadIdx.x], hist[threadIdx.x]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = __hip_atomic_fetch_add(&ws->done[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket == gridDim.x - 1) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        resolve_digit(ws, p, k);
+    }
 }
 
 __device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
@@ -76,8 +129,8 @@ __device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
 }
 
 // pass 0: build the keys, histogram of digit 7, class / violated / positive counts
-__global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n, const double *eig, const double *obj,
-                                                             uint64_t *keys, TopkWs *ws)
+__global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n, int64_t k, const double *eig,
+                                                             const double *obj, uint64_t *keys, TopkWs *ws)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cnt[3];
@@ -85,22 +138,29 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
     uint32_t c_class = 0, c_viol = 0, c_pos = 0;
-    for (int64_t i = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * TK_THREADS) {
-        const double e = eig ? eig[i] : 0.0, o = obj ? obj[i] : 0.0;
-        const uint64_t key = masked_key(mode, e, o);
-        keys[i] = key;
-        atomicAdd(&hist[key >> 56], 1u);
-        c_class += (mode == TK_MODE_OPT) ? 1u : (key != 0ull);
-        c_viol += (eig != nullptr) && (e < SDPCUT_NEG_EIGVAL);
-        c_pos += (obj != nullptr) && (o > 0.0);
+    const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
+    const int64_t rounds = (n + stride - 1) / stride;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+        const bool in = i < n;
+        uint64_t key = 0;
+        if (in) {
+            const double e = eig ? eig[i] : 0.0, o = obj ? obj[i] : 0.0;
+            key = masked_key(mode, e, o);
+            keys[i] = key;
+            c_class += (mode == TK_MODE_OPT) ? 1u : (key != 0ull);
+            c_viol += (eig != nullptr) && (e < SDPCUT_NEG_EIGVAL);
+            c_pos += (obj != nullptr) && (o > 0.0);
+        }
+        hist_add(hist, (uint32_t)(key >> 56), in);
     }
-    atomicAdd(&cnt[0], c_class);
-    atomicAdd(&cnt[1], c_viol);
-    atomicAdd(&cnt[2], c_pos);
+    if (c_class) atomicAdd(&cnt[0], c_class);
+    if (c_viol) atomicAdd(&cnt[1], c_viol);
+    if (c_pos) atomicAdd(&cnt[2], c_pos);
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&ws->hist[0][threadIdx.x], hist[threadIdx.x]);
     if (threadIdx.x < 3 && cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&ws->counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    finish_pass(ws, 0, k, hist);
 }
 
 // pass p = 1..7: histogram of digit 7-p among the keys that match the prefix resolved so far
@@ -108,127 +168,189 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
 {
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
-    const Resolved r = resolve_prefix(ws, p, k);     // contains __syncthreads
-    if (r.need < 1) return;                          // uniform: empty class
-    const int shift = 8 * (7 - p);
-    for (int64_t i = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * TK_THREADS) {
-        const uint64_t key = keys[i];
-        if (((key ^ r.prefix) >> (shift + 8)) == 0) atomicAdd(&hist[(key >> shift) & 255], 1u);
-    }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][threadIdx.x], hist[threadIdx.x]);
-}
-
-// threshold known: collect keys above it (any order) and count the keys equal to it per block
-__global__ __launch_bounds__(TK_THREADS) void tk_collect_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
-                                                                TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx)
-{
-    __shared__ uint32_t eq;
-    if (threadIdx.x == 0) eq = 0;
-    const Resolved r = resolve_prefix(ws, 8, k);
-    if (r.need < 1) return;
-    const uint64_t T = r.prefix;
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    uint32_t my_eq = 0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) {
-        const uint64_t key = keys[i];
-        if (key > T) {
-            const uint32_t slot = atomicAdd(&ws->gt_counter, 1u);
-            sel_key[slot] = key;
-            sel_idx[slot] = (uint32_t)i;
+    const TkState st = ws->state[p];
+    if (st.need >= 1) {                               // uniform
+        const int shift = 8 * (7 - p);
+        const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
+        const int64_t rounds = (n + stride - 1) / stride;
+        for (int64_t r = 0; r < rounds; ++r) {
+            const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+            const uint64_t key = (i < n) ? keys[i] : 0ull;
+            const bool match = (i < n) && (((key ^ st.prefix) >> (shift + 8)) == 0);
+            hist_add(hist, (uint32_t)((key >> shift) & 255), match);
         }
-        my_eq += (key == T);
-    }
-    if (my_eq) atomicAdd(&eq, my_eq);
-    __syncthreads();
-    if (threadIdx.x == 0) ws->blk_eq[blockIdx.x] = eq;
-}
-
-// keys equal to the threshold: the `need` lowest indices, placed behind the greater ones
-__global__ __launch_bounds__(TK_THREADS) void tk_equal_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
-                                                              TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx)
-{
-    __shared__ uint32_t red[TK_THREADS];
-    __shared__ uint32_t wave_cnt[TK_THREADS / 64];
-    const Resolved r = resolve_prefix(ws, 8, k);
-    if (r.need < 1) return;
-    const uint64_t T = r.prefix;
-    const int64_t k_eff = k < ws->counters[0] ? k : ws->counters[0];
-    const int64_t greater = k_eff - r.need;
-    // equal keys in the blocks before this one
-    uint32_t part = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += TK_THREADS) part += ws->blk_eq[b];
-    red[threadIdx.x] = part;
-    __syncthreads();
-    for (int off = TK_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    int64_t base = red[0];
-    if (base >= r.need || ws->blk_eq[blockIdx.x] == 0) return;   // uniform
+    finish_pass(ws, p, k, hist);
+}
+
+// threshold known: per block (contiguous chunk of the index space) count the keys above it and
+// the keys equal to it -- no global atomics, the write pass derives its offsets from these
+__global__ __launch_bounds__(TK_THREADS) void tk_count_kernel(int64_t n, int64_t chunk, const uint64_t *keys, TopkWs *ws)
+{
+    __shared__ uint32_t c_gt, c_eq;
+    if (threadIdx.x == 0) { c_gt = 0; c_eq = 0; }
+    __syncthreads();
+    const TkState st = ws->state[8];
+    if (st.need < 1) return;
+    const uint64_t T = st.prefix;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    uint32_t my_gt = 0, my_eq = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) {
+        const uint64_t key = keys[i];
+        my_gt += (key > T);
+        my_eq += (key == T);
+    }
+    if (my_gt) atomicAdd(&c_gt, my_gt);
+    if (my_eq) atomicAdd(&c_eq, my_eq);
+    __syncthreads();
+    if (threadIdx.x == 0) { ws->blk_gt[blockIdx.x] = c_gt; ws->blk_eq[blockIdx.x] = c_eq; }
+}
+
+// write pass: keys above the threshold go to slots [0, greater) (order inside a block is free,
+// the final sort fixes it); of the keys equal to it the `need` lowest indices follow
+__global__ __launch_bounds__(TK_THREADS) void tk_write_kernel(int64_t n, int64_t chunk, const uint64_t *keys, TopkWs *ws,
+                                                              uint64_t *sel_key, uint32_t *sel_idx)
+{
+    __shared__ uint32_t red_gt[TK_THREADS], red_eq[TK_THREADS];
+    __shared__ uint32_t wave_cnt[TK_THREADS / 64];
+    __shared__ uint32_t gt_local;
+    const TkState st = ws->state[8];
+    if (st.need < 1) return;
+    const uint64_t T = st.prefix;
+    const int64_t greater = ws->counters[3] - st.need;
+    uint32_t pg = 0, pe = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += TK_THREADS) { pg += ws->blk_gt[b]; pe += ws->blk_eq[b]; }
+    red_gt[threadIdx.x] = pg;
+    red_eq[threadIdx.x] = pe;
+    if (threadIdx.x == 0) gt_local = 0;
+    __syncthreads();
+    for (int off = TK_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { red_gt[threadIdx.x] += red_gt[threadIdx.x + off]; red_eq[threadIdx.x] += red_eq[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    const int64_t base_gt = red_gt[0];
+    int64_t base_eq = red_eq[0];
+    const bool want_gt = ws->blk_gt[blockIdx.x] != 0;
+    const bool want_eq = ws->blk_eq[blockIdx.x] != 0 && base_eq < st.need;
+    if (!want_gt && !want_eq) return;     // uniform
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t row = lo; row < hi; row += TK_THREADS) {
         const int64_t i = row + threadIdx.x;
-        const bool is_eq = (i < hi) && (keys[i] == T);
-        const unsigned long long m = __ballot(is_eq);
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        uint32_t row_total = 0;
-        for (int w = 0; w < TK_THREADS / 64; ++w) {
-            if (w < wave) before += wave_cnt[w];
-            row_total += wave_cnt[w];
+        const uint64_t key = (i < hi) ? keys[i] : 0ull;
+        if (i < hi && key > T) {
+            const int64_t slot = base_gt + atomicAdd(&gt_local, 1u);
+            sel_key[slot] = key;
+            sel_idx[slot] = (uint32_t)i;
         }
-        const int64_t rank = base + before;
-        if (is_eq && rank < r.need) {
-            sel_key[greater + rank] = T;
-            sel_idx[greater + rank] = (uint32_t)i;
+        if (want_eq) {     // uniform
+            const bool is_eq = (i < hi) && (key == T);
+            const unsigned long long m = __ballot(is_eq);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t row_total = 0;
+            for (int w = 0; w < TK_THREADS / 64; ++w) {
+                if (w < wave) before += wave_cnt[w];
+                row_total += wave_cnt[w];
+            }
+            const int64_t rank = base_eq + before;
+            if (is_eq && rank < st.need) {
+                sel_key[greater + rank] = T;
+                sel_idx[greater + rank] = (uint32_t)i;
+            }
+            base_eq += row_total;
+            __syncthreads();
         }
-        base += row_total;
-        __syncthreads();
-        if (base >= r.need) break;   // uniform
     }
 }
 
-// one workgroup: bitonic sort of the selected pairs by (key desc, idx asc), then emit
-__global__ __launch_bounds__(1024) void tk_sort_emit_kernel(int64_t k, int64_t base, double score_add, const TopkWs *ws,
-                                                            const uint64_t *sel_key, const uint32_t *sel_idx,
-                                                            int64_t *idx_out, double *score_out)
+// Final order of the selected pairs, (key desc, idx asc) = ascending composite (~key, idx):
+//   1. tk_tilesort_kernel: bitonic sort of 512-entry tiles in LDS (one workgroup per tile);
+//   2. tk_mergerank_kernel: every entry's final rank = its position in its own tile + the number
+//      of entries preceding it in every other tile (binary searches over tiles staged in LDS;
+//      composites are unique, so ranks are a permutation).
+// ~k log k work instead of the k^2 of a counting sort, two short launches.
+#define TK_TILE 512
+
+__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib)
 {
-    __shared__ uint64_t sk[TK_MAXK];
-    __shared__ uint32_t si[TK_MAXK];
-    const int64_t k_eff = k < ws->counters[0] ? k : ws->counters[0];
-    if (k_eff < 1) return;
-    int P = 2;
-    while (P < k_eff) P <<= 1;
-    for (int t = threadIdx.x; t < P; t += 1024) {
-        // ascending order on (~key, idx)  ==  descending key, ascending index; padding sorts last
-        sk[t] = (t < k_eff) ? ~sel_key[t] : ~0ull;
-        si[t] = (t < k_eff) ? sel_idx[t] : 0xffffffffu;
+    return (ka < kb) || (ka == kb && ia < ib);
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *ws, const uint64_t *sel_key,
+                                                                 const uint32_t *sel_idx, uint64_t *tile_key,
+                                                                 uint32_t *tile_idx)
+{
+    __shared__ uint64_t sk[TK_TILE];
+    __shared__ uint32_t si[TK_TILE];
+    const int k_eff = (int)ws->counters[3];
+    const int lo = blockIdx.x * TK_TILE;
+    if (lo >= k_eff) return;                       // uniform
+    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
+        const int j = lo + t;
+        sk[t] = (j < k_eff) ? ~sel_key[j] : ~0ull;       // padding sorts last
+        si[t] = (j < k_eff) ? sel_idx[j] : 0xffffffffu;
     }
     __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
+    for (int size = 2; size <= TK_TILE; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < P / 2; t += 1024) {
-                const int pos = 2 * t - (t & (stride - 1));
-                const int par = pos + stride;
-                const bool up = (pos & size) == 0;
-                const uint64_t ka = sk[pos], kb = sk[par];
-                const uint32_t ia = si[pos], ib = si[par];
-                const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
-                if (a_gt_b == up) {
-                    sk[pos] = kb; sk[par] = ka;
-                    si[pos] = ib; si[par] = ia;
-                }
+            const int t = threadIdx.x;
+            const int pos = 2 * t - (t & (stride - 1));
+            const int par = pos + stride;
+            const bool up = (pos & size) == 0;
+            const uint64_t ka = sk[pos], kb = sk[par];
+            const uint32_t ia = si[pos], ib = si[par];
+            if (comp_less(kb, ib, ka, ia) == up) {
+                sk[pos] = kb; sk[par] = ka;
+                si[pos] = ib; si[par] = ia;
             }
             __syncthreads();
         }
     }
-    for (int t = threadIdx.x; t < k_eff; t += 1024) {
-        idx_out[t] = base + (int64_t)si[t];
-        score_out[t] = score_of(~sk[t]) + score_add;
+    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
+        tile_key[lo + t] = sk[t];
+        tile_idx[lo + t] = si[t];
     }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
+                                                                  const uint64_t *tile_key, const uint32_t *tile_idx,
+                                                                  int64_t *idx_out, double *score_out)
+{
+    __shared__ uint64_t sk[TK_MAXK];
+    __shared__ uint32_t si[TK_MAXK];
+    const int k_eff = (int)ws->counters[3];
+    if (blockIdx.x * TK_THREADS >= k_eff) return;   // uniform
+    const int ntiles = (k_eff + TK_TILE - 1) / TK_TILE;
+    for (int j = threadIdx.x; j < ntiles * TK_TILE; j += TK_THREADS) {
+        sk[j] = tile_key[j];
+        si[j] = tile_idx[j];
+    }
+    __syncthreads();
+    const int e = blockIdx.x * TK_THREADS + threadIdx.x;      // position in the tiled array
+    if (e >= ntiles * TK_TILE) return;
+    const uint64_t ke = sk[e];
+    const uint32_t ie = si[e];
+    if (ie == 0xffffffffu && ke == ~0ull) return;             // padding
+    const int te = e / TK_TILE;
+    int rank = e - te * TK_TILE;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t == te) continue;
+        // lower bound of e's composite inside tile t (all composites are distinct)
+        int lo = 0, hi = TK_TILE;
+        while (lo < hi) {                                     // <= 10 steps
+            const int mid = (lo + hi) >> 1;
+            const bool less = comp_less(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie);
+            lo = less ? mid + 1 : lo;
+            hi = less ? hi : mid;
+        }
+        rank += lo;
+    }
+    idx_out[rank] = base + (int64_t)ie;
+    score_out[rank] = score_of(~ke) + score_add;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -236,8 +358,9 @@ int ensure_topk_ws(sdpcut_ctx *h)
 {
     if (h->d_topk_ws) return 0;
     HIP_TRY(h, hipMalloc(&h->d_topk_ws, sizeof(TopkWs)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_sel_key, TK_MAXK * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_sel_idx, TK_MAXK * sizeof(uint32_t)));
+    // first half: compacted selection, second half: the sorted tiles
+    HIP_TRY(h, hipMalloc((void **)&h->d_sel_key, 2 * TK_MAXK * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_sel_idx, 2 * TK_MAXK * sizeof(uint32_t)));
     return 0;
 }
 
@@ -247,10 +370,11 @@ void free_topk_ws(sdpcut_ctx *h)
     h->d_topk_ws = nullptr; h->d_sel_key = nullptr; h->d_sel_idx = nullptr;
 }
 
-// Head of a ranking by selection.  mode: 1 feasibility, 2 optimality, 3 strong class.  Writes
-// min(k, class size) entries; class size and the violated / positive counts come back in cnt[0..2].
-int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                          double *d_score_out, int64_t cnt[4])
+// Enqueue the selection of the head of a ranking (no host synchronisation).
+// mode: 1 feasibility, 2 optimality, 3 strong class.  min(k, class size) entries are written.
+// *d_counters_out receives the device address of {class size, nb_violated, nb_positive, k_eff}.
+int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
+                        double *d_score_out, const int64_t **d_counters_out)
 {
     const int64_t n = h->N;
     if (k < 1 || k > TK_MAXK || n < 1) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k out of range");
@@ -264,19 +388,33 @@ int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, 
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
-    hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, eig, obj, h->d_key_a, ws);
+    hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
     for (int p = 1; p < 8; ++p)
         hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, p, n, k, h->d_key_a, ws);
     int64_t chunk = (n + grid - 1) / grid;
     chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
-    hipLaunchKernelGGL(tk_collect_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+    hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
+    hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
                        h->d_sel_key, h->d_sel_idx);
-    hipLaunchKernelGGL(tk_equal_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                       h->d_sel_key, h->d_sel_idx);
-    hipLaunchKernelGGL(tk_sort_emit_kernel, dim3(1), dim3(1024), 0, h->stream, k, h->base, score_add, ws, h->d_sel_key,
-                       h->d_sel_idx, d_idx_out, d_score_out);
+    const int ntiles = (int)((k + TK_TILE - 1) / TK_TILE);
+    uint64_t *tile_key = h->d_sel_key + TK_MAXK;
+    uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
+    hipLaunchKernelGGL(tk_tilesort_kernel, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key, h->d_sel_idx,
+                       tile_key, tile_idx);
+    hipLaunchKernelGGL(tk_mergerank_kernel, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
+                       h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(cnt, ws->counters, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    if (d_counters_out) *d_counters_out = ws->counters;
+    return 0;
+}
+
+int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
+                          double *d_score_out, int64_t cnt[4])
+{
+    const int64_t *d_cnt = nullptr;
+    int rc = topk_select_enqueue(h, mode, k, score_add, d_idx_out, d_score_out, &d_cnt);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(cnt, d_cnt, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return 0;
 }

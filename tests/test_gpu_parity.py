@@ -529,3 +529,27 @@ def test_rank_list_tail_comes_from_full_sort(lib, golden_boxqp):
     assert [e[0] for e in rl] == g[tag + "_rnd_s4_order"].tolist()
     rl2 = cs._sel_eigcut_by_ordering_on_measure(2, vv, 1)
     assert [e[0] for e in rl2] == g[tag + "_rnd_s2_order"].tolist()
+
+
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_select_round_equals_separate_calls(full_c2, scorer, strat):
+    """The fused per-round entry point returns exactly what score + rank + cut_rows return."""
+    from sdpcutsel_via_nn_amd import _capi
+    wl, eig, obj = full_c2
+    scorer.set_instance(100, wl["Q_arr"])          # other tests re-bind the shared handle
+    scorer.set_candidates(wl["set_inds"], wl["ks"])
+    scorer.set_point(wl["vars_values"])
+    for sel in (5000, 33):
+        r = scorer.select_round(strat, sel)
+        r = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+        ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=sel)
+        lam, coef, rhs, cols, ks = scorer.cut_rows(ids)
+        assert np.array_equal(r["idx"], ids) and np.array_equal(r["score"], score)
+        assert r["n_total"] == total and r["new_strat"] == new_strat and r["counters"] == cnt
+        ld = r["coef"].shape[1]                     # 9 = row length of a 3-variable cut
+        assert ld == 9 and np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :ld])
+        assert not coef[:, ld:].any()
+        assert np.array_equal(r["rhs"], rhs) and np.array_equal(r["ks"], ks)
+        if ids.size:
+            assert np.abs(lam - eig[ids]).max() <= 1e-15
+    assert scorer.select_round(strat, 0)["idx"].size == 0

@@ -66,12 +66,29 @@ __device__ __forceinline__ double rcp_nr(double d)
     r = fma(fma(-d, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ double tansig_fast(double n)
+__device__ __forceinline__ double tansig_fast(double n)      // = tansig() of csrc/score.hip
 {
-    double y = -2.0 * n;
-    y = fmin(fmax(y, -80.0), 80.0);
-    const double e = exp_fast(y);
-    return fma(2.0, rcp_nr(e + 1.0), -1.0);
+    const double y8 = fmin(n * -0.25, 88.0);
+    const double k = rint(y8 * 11.541560327111707259);
+    double r = fma(k, -8.66433975461404770613e-02, y8);
+    r = fma(k, -2.38526866158823462503e-11, r);
+    double p = 2.48015873015873015873e-05;
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const double d = ldexp(p, (int)k) + 1.0;
+    double q = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, q, 1.0);
+    q = fma(q, fma(e, e, e), q);
+    return fma(2.0, q, -1.0);
 }
 
 template <int V>
@@ -139,7 +156,7 @@ int main()
     {
         const int n = 1 << 20;
         std::vector<double> h(n), a(n), b(n), c(n), d(n), e(n);
-        for (int i = 0; i < n; ++i) h[i] = -30.0 + 60.0 * i / n;
+        for (int i = 0; i < n; ++i) h[i] = (i & 1) ? -30.0 + 60.0 * i / n : -400.0 + 800.0 * i / n;   // fine + wide sweep
         double *din, *d0, *d1, *d2, *d3, *d4_;
         CHECK(hipMalloc(&din, n * 8)); CHECK(hipMalloc(&d0, n * 8)); CHECK(hipMalloc(&d1, n * 8));
         CHECK(hipMalloc(&d2, n * 8)); CHECK(hipMalloc(&d3, n * 8)); CHECK(hipMalloc(&d4_, n * 8));
