@@ -139,6 +139,10 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         tflops = FLOPS_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e12
         gbs = BYTES_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "score_kernel_traffic.json")
+        if os.path.exists(tfile):      # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes)
+            traffic = json.load(open(tfile)).get(args.kernel)
         out = {
             "metric": "candidate cuts scored/sec (eig+NN)", "value": total / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -148,7 +152,7 @@ def main():
                        "candidates_per_gpu": N_PER_GPU, "nb_vars": NB_VARS, "k": K, "sel_size": SEL,
                        "kernel": args.kernel, "strategy": 4},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": {"mfma": "score_mfma_kernel<3,50,3>", "valu": "score_valu_kernel<3,50,3>", "simple": "score_simple_kernel<3>"}[args.kernel],
                          "kernel_ms": k_ms, "flops_per_candidate": FLOPS_PER_CAND[K],
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
