@@ -70,10 +70,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                      % (args.gpus, args.gpus))
+    # rehearsal knobs (one-GPU box): SDPCUT_BENCH_BACKEND=gloo stages the all-gather through the
+    # host, SDPCUT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
+    backend = os.environ.get("SDPCUT_BENCH_BACKEND", "nccl")
+    if os.environ.get("SDPCUT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -130,7 +138,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

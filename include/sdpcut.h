@@ -68,8 +68,10 @@ const char *sdpcut_last_error(sdpcut_handle h); /* h may be NULL: error of the l
 int sdpcut_create(int device_id, sdpcut_handle *out);
 int sdpcut_destroy(sdpcut_handle h);
 int sdpcut_set_option(sdpcut_handle h, int option, int64_t value);
-/* Run all work of this handle on an existing HIP stream (hipStream_t passed as void*);
- * NULL restores the handle's own non-blocking stream. */
+/* Run all work of this handle on an existing HIP stream (hipStream_t passed as void*).
+ * NULL is the HIP null stream (what PyTorch calls its default stream);
+ * SDPCUT_OWN_STREAM restores the handle's own non-blocking stream. */
+#define SDPCUT_OWN_STREAM ((void *)(intptr_t)-1)
 int sdpcut_set_stream(sdpcut_handle h, void *hip_stream);
 int sdpcut_synchronize(sdpcut_handle h);
 

@@ -134,7 +134,10 @@ class Scorer(object):
         self._check(self._lib.sdpcut_set_option(self._h, option, int(value)))
 
     def set_stream(self, stream_ptr):
-        self._check(self._lib.sdpcut_set_stream(self._h, _vp(stream_ptr) if stream_ptr else None))
+        """stream_ptr: a hipStream_t as int (0 = the null stream, PyTorch's default stream);
+        None restores the handle's own stream."""
+        arg = _vp(-1 & 0xFFFFFFFFFFFFFFFF) if stream_ptr is None else (_vp(stream_ptr) if stream_ptr else None)
+        self._check(self._lib.sdpcut_set_stream(self._h, arg))
 
     def synchronize(self):
         self._check(self._lib.sdpcut_synchronize(self._h))

@@ -107,7 +107,7 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
 int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
 {
     if (!h) return SDPCUT_EINVAL;
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hip_stream == SDPCUT_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
     return SDPCUT_OK;
 }
 

@@ -92,15 +92,32 @@ class ShardedSelector(object):
         return torch.cat(parts).to(t.device)
 
     def _global_head(self, strat, sel_size, count, want_secondary=False):
-        """Merged head of one ranking: (scores, ids, global list length, summed counters)."""
+        """Merged head of one ranking: (scores, ids, global list length, summed counters).
+
+        ONE collective per head: every rank contributes a packed int64 record
+        [total, nb_violated, strong, violated, nb_positive, 0, 0, 0 | scores | ids | secondary]
+        (fp64 fields bit-cast), so the counters travel with the data instead of in a separate
+        all-reduce; these messages are latency-bound (<= 120 KB per rank), fewer is faster."""
         s, i, sec, total, cnt = self.ops.local_head(strat, sel_size, count, want_secondary)
-        g_total, nv, strong, viol, npos = self._sum(total, cnt["nb_violated"], cnt["strong"], cnt["violated"],
-                                                    cnt["nb_positive"])
-        if self.world > 1:
-            sec_all = self._all_gather(sec) if sec is not None else None
-            s, i = self.ops.merge(self._all_gather(s), self._all_gather(i), count, sec_all)
-        valid = min(count, g_total)
-        return s[:valid], i[:valid], g_total, dict(nb_violated=nv, strong=strong, violated=viol, nb_positive=npos)
+        head = [total, cnt["nb_violated"], cnt["strong"], cnt["violated"], cnt["nb_positive"]]
+        if self.world == 1:
+            g = head
+        else:
+            nf = 3 if sec is not None else 2
+            rec = torch.empty(8 + nf * count, dtype=torch.int64, device=s.device)
+            rec[:8] = torch.tensor(head + [0, 0, 0], dtype=torch.int64).to(s.device)
+            rec[8:8 + count] = s.view(torch.int64)
+            rec[8 + count:8 + 2 * count] = i
+            if sec is not None:
+                rec[8 + 2 * count:] = sec.view(torch.int64)
+            allrec = self._all_gather(rec).view(self.world, -1)
+            g = [int(v) for v in allrec[:, :5].sum(dim=0).cpu()]
+            s_all = allrec[:, 8:8 + count].contiguous().view(-1).view(torch.float64)
+            i_all = allrec[:, 8 + count:8 + 2 * count].contiguous().view(-1)
+            sec_all = allrec[:, 8 + 2 * count:].contiguous().view(-1).view(torch.float64) if sec is not None else None
+            s, i = self.ops.merge(s_all, i_all, count, sec_all)
+        valid = min(count, g[0])
+        return s[:valid], i[:valid], g[0], dict(nb_violated=g[1], strong=g[2], violated=g[3], nb_positive=g[4])
 
     # -- selection -----------------------------------------------------------------------
     def select(self, strat, sel_size):
