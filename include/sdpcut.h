@@ -201,6 +201,18 @@ int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs,
  * SDPCUT_OPT_TIMING = 1).  ms[0] = score kernels, ms[1] = rank. */
 int sdpcut_last_timing(sdpcut_handle h, double *ms, int n);
 
+/*
+ * Semidefinite vertex cover P^E_dim (replaces the index-set enumeration of
+ * _get_sdp_vertex_cover, cut_select_qp.py:399-524, ch_ext = 0): every clique of size `dim`
+ * of the sparsity graph plus every maximal clique of size 2..dim-1, in the reference's order.
+ * adjacency is [nb_vars][nb_vars] bytes (non-zero = edge; symmetrised, diagonal ignored).
+ * Writes at most max_out rows of set_inds_out [.][5] (padded with -1) / ks_out and always the
+ * full count (call with max_out = 0 to size the arrays; the reference bails out at 4e6,
+ * _THRES_MAX_SUBS).  Host function, no handle needed.
+ */
+int sdpcut_enumerate_cover(int32_t nb_vars, const uint8_t *adjacency, int32_t dim, int64_t max_out,
+                           int32_t *set_inds_out, int32_t *ks_out, int64_t *count_out);
+
 /* Self-test hook: multiplies A[16x4] * B[4x16] with v_mfma_f64_16x16x4_f64 using the
  * fragment maps the MLP kernel assumes; C row-major [16][16]. */
 int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C);

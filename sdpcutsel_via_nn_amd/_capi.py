@@ -53,6 +53,7 @@ SIGNATURES = {
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
     "sdpcut_mfma_probe": [_vp, _dp, _dp, _dp],
+    "sdpcut_enumerate_cover": [_c.c_int32, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i32p, _i32p, _i64p],
 }
 _RESTYPES = {"sdpcut_last_error": _c.c_char_p}
 
@@ -92,6 +93,31 @@ def _ptr(a, typ):
 
 class SdpCutError(RuntimeError):
     pass
+
+
+def enumerate_cover(adjacency, dim, max_subs=None):
+    """Index sets of the semidefinite vertex cover P^E_dim in the reference's order
+    (cut_select_qp.py:399-524).  adjacency: [n, n] array, non-zero = edge.
+    -> (set_inds int32 [N, 5] padded with -1, ks int32 [N], N).  If max_subs is given and
+    N >= max_subs only the count is returned (arrays None), like the reference's RAM guard."""
+    lib = load_library()
+    adj = np.ascontiguousarray(np.asarray(adjacency) != 0, dtype=np.uint8)
+    n = adj.shape[0]
+    if adj.shape != (n, n):
+        raise ValueError("adjacency must be square")
+    cnt = _c.c_int64(0)
+    u8 = adj.ctypes.data_as(_c.POINTER(_c.c_uint8))
+    rc = lib.sdpcut_enumerate_cover(n, u8, int(dim), 0, None, None, ctypes.byref(cnt))
+    if rc != 0:
+        raise ValueError("sdpcut_enumerate_cover: bad arguments (dim must be 3..5)")
+    N = cnt.value
+    if max_subs is not None and N >= max_subs:
+        return None, None, N
+    sets = np.empty((max(N, 1), 5), dtype=np.int32)
+    ks = np.empty(max(N, 1), dtype=np.int32)
+    rc = lib.sdpcut_enumerate_cover(n, u8, int(dim), N, _ptr(sets, _i32p), _ptr(ks, _i32p), ctypes.byref(cnt))
+    assert rc == 0 and cnt.value == N
+    return sets[:N], ks[:N], N
 
 
 class Scorer(object):

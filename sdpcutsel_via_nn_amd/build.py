@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdpcut_hip.so")
-SOURCES = ["score.hip", "rank.hip", "topk.hip", "capi.hip"]
+SOURCES = ["score.hip", "rank.hip", "topk.hip", "capi.hip", "cover.cpp"]
 HEADERS = ["common.h", "jacobi.h", "keys.h", os.path.join("..", "..", "include", "sdpcut.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -32,7 +32,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]

@@ -43,10 +43,12 @@ class FeasEntry(tuple):
     """``(set_inds, -eigval, Xarr_inds, dim_act)`` of cut_select_qp.py:649, remembering which
     candidate it came from so that cut generation needs no search."""
     agg_idx = -1
+    binding = None
 
-    def __new__(cls, items, agg_idx):
+    def __new__(cls, items, agg_idx, binding=None):
         self = super().__new__(cls, items)
         self.agg_idx = agg_idx
+        self.binding = binding
         return self
 
 
@@ -93,7 +95,7 @@ class RankList(Sequence):
         idx, score = int(self._idx[pos]), float(self._score[pos])
         set_inds, Xarr_inds = self._b.agg_entry(idx)
         if self._kind == 1:
-            return FeasEntry((set_inds, score, Xarr_inds, len(set_inds)), idx)
+            return FeasEntry((set_inds, score, Xarr_inds, len(set_inds)), idx, self._b)
         L = self._b.nb_lifted
         curr_pt = tuple(self._vv[L + i] for i in set_inds)
         X_slice = tuple(self._vv[i] for i in Xarr_inds)
@@ -151,6 +153,34 @@ class _Binding(object):
         return s, pos
 
 
+class AggArrays(Sequence):
+    """Array-backed ``agg_list``: the candidate records of cut_select_qp.py:529-540 built on
+    demand.  A Python list of 1.7e6 tuples (spar125-075-1, dim 4) takes minutes to build and
+    GBs to hold; the loop only ever reads ``[0]`` / ``[1]`` of the few thousand selected entries."""
+
+    def __init__(self, set_inds, ks, nb_vars, Q_arr=None):
+        self.set_inds = np.ascontiguousarray(set_inds, dtype=np.int32)
+        self.ks = np.ascontiguousarray(ks, dtype=np.int32)
+        self.nb_vars, self.Q_arr = nb_vars, Q_arr
+
+    def __len__(self):
+        return self.ks.shape[0]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return [self[i] for i in range(*idx.indices(len(self)))]
+        k = int(self.ks[idx])
+        s = [int(v) for v in self.set_inds[idx, :k]]
+        n = self.nb_vars
+        pos = [n * s[a] - s[a] * (s[a] + 1) // 2 + s[b] for a in range(k) for b in range(a, k)]
+        if self.Q_arr is None:
+            return (s, pos, None, None)
+        q = [self.Q_arr[p] for p in pos]
+        max_elem = k * abs(max(q, key=abs))
+        max_elem += 1 if not max_elem else 0
+        return (s, pos, tuple(np.divide(q, max_elem)), max_elem)
+
+
 class GpuCutSelectionMixin(object):
     """The four hot-path methods of the reference's ``CutSolver`` on the GPU."""
 
@@ -189,12 +219,15 @@ class GpuCutSelectionMixin(object):
         if b is not None and b.agg_list is agg and b.n_at_bind == len(agg):
             return b
         N = len(agg)
-        S = np.full((max(N, 1), 5), -1, dtype=np.int32)
-        ks = np.zeros(max(N, 1), dtype=np.int32)
-        for i, e in enumerate(agg):
-            s = e[0]
-            ks[i] = len(s)
-            S[i, :len(s)] = s
+        if isinstance(agg, AggArrays):          # enumerated on our side: the arrays already exist
+            S, ks = agg.set_inds, agg.ks
+        else:
+            S = np.full((max(N, 1), 5), -1, dtype=np.int32)
+            ks = np.zeros(max(N, 1), dtype=np.int32)
+            for i, e in enumerate(agg):
+                s = e[0]
+                ks[i] = len(s)
+                S[i, :len(s)] = s
         sc = self._gpu_new_scorer()
         sc.set_instance(self._nb_vars, np.asarray(self._Q_arr, dtype=np.float64))
         sc.set_candidates(S[:N], ks[:N])
@@ -303,10 +336,9 @@ class GpuCutSelectionMixin(object):
     def _find_binding_for(self, entries):
         """Binding whose candidate list ALL the FeasEntry objects index, else None (the QCQP
         feasibility-only round mixes entries of two lists, cut_select_qcqp.py:79)."""
-        for b in getattr(self, "_gpu_bindings", {}).values():
-            if b.agg_list is not None and all(
-                    e.agg_idx < len(b.agg_list) and b.agg_list[e.agg_idx][0] is e[0] for e in entries):
-                return b
+        b = entries[0].binding
+        if b is not None and all(e.binding is b for e in entries):
+            return b
         return None
 
     def _gen_from_entries(self, entries, feas_sel, vars_values, pair):
@@ -392,6 +424,68 @@ class CutSolver(GpuCutSelectionMixin):
         s = min(int(np.floor(sel_size * nb_subprobs)) if sel_size < 1 else min(sel_size, nb_subprobs),
                 CutSolver._SDP_CUTS_PER_ROUND_MAX)
         return max(s, minimum)
+
+    # ------------------------------------------------------------------ round harness (SURVEY 8 f row 2)
+    _CONVERGENCE_TOL = 10 ** (-3)         # cut_select_qp.py:29
+
+    def cut_select_algo(self, filename, dim, sel_size, strat=2, nb_rounds_cuts=20, term_on=False,
+                        strong_only=False):
+        """Algorithm 1 on a BoxQP ``.in`` file without CPLEX: the call sequence of
+        cut_select_qp.py:73-221 (parse -> vertex cover -> McCormick relaxation -> rounds of
+        [select, generate, re-solve]) with scipy's HiGHS as LP solver, our C++ cover
+        enumeration and the GPU-backed selection methods.  Triangle cuts, dense cuts
+        (strat 0), exact-SDP strategies and chordal extensions are out of scope.
+        Returns the reference's default tuple
+        (bounds per round, total time, round times, separation times, nb cuts per round, [], nb candidates)."""
+        from timeit import default_timer as timer
+        from . import harness
+        assert strat in (1, 2, 4, 5), "strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random"
+        assert 0 < sel_size, "The selection size must be a % or number (of cuts) >0!"
+        assert dim <= 5, "Keep SDP vertex cover low-dimensional (<=5)!"
+        time_begin = timer()
+        nbs_sdp_cuts, curr_obj_vals, round_times, sep_times = [0], [], [], []
+        self._dim = dim
+        if strat in (2, 4):
+            self._load_neural_nets()
+        inst = harness.parse_boxqp(filename)
+        self._nb_vars, self._nb_lifted, self._Q_arr = inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
+        self._my_prob = my_prob = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
+        set_inds, ks, nb_subprobs = _capi.enumerate_cover(inst["adj"], dim, max_subs=self._THRES_MAX_SUBS)
+        if nb_subprobs >= self._THRES_MAX_SUBS or nb_rounds_cuts == 0:          # :117-120
+            return [0, 0], timer() - time_begin, 0, 0, [0], 0, nb_subprobs
+        self._agg_list = AggArrays(set_inds, ks, self._nb_vars, self._Q_arr)
+        sel_size = self.selection_size(sel_size, nb_subprobs)
+        t0 = timer()
+        my_prob.linear_constraints.add(*harness.mccormick_rows(self._nb_vars, inst["adj"]))
+        sep_times.append(timer() - t0)
+        t0 = timer()
+        my_prob.solve()
+        round_times.append(timer() - t0 + sep_times[0])
+        curr_obj_vals.append(my_prob.get_objective_value())
+        vars_values = np.array(my_prob.get_values())
+        strat_change = strat
+        for cut_round in range(1, nb_rounds_cuts + 1):
+            if (term_on and len(curr_obj_vals) >= 3 and curr_obj_vals[-1] != curr_obj_vals[0] and
+                    (curr_obj_vals[-1] - curr_obj_vals[-2]) / (curr_obj_vals[-1] - curr_obj_vals[0])
+                    < self._CONVERGENCE_TOL):
+                break                                                              # :153-156
+            t_sep = timer()
+            if strat == 4:
+                res = self._sel_eigcut_by_ordering_on_measure(strat, vars_values, cut_round, sel_size=sel_size)
+                strat_change, rank_list = res if isinstance(res, tuple) else (strat, res)
+            else:
+                rank_list = self._sel_eigcut_by_ordering_on_measure(strat, vars_values, cut_round)
+            nbs_sdp_cuts.append(self._gen_eigcuts_selected(strat, sel_size, rank_list, strong_only=strong_only,
+                                                           vars_values=vars_values))
+            sep_times.append(timer() - t_sep)
+            strat = strat_change                                                   # :188
+            t0 = timer()
+            my_prob.solve()
+            round_times.append(timer() - t0 + sep_times[-1])
+            curr_obj_vals.append(my_prob.get_objective_value())
+            vars_values = np.array(my_prob.get_values()).astype(float)
+        return ([-obj for obj in curr_obj_vals], timer() - time_begin, round_times, sep_times, nbs_sdp_cuts, [],
+                nb_subprobs)
 
 
 class CutSolverQCQP(CutSolver):
