@@ -13,22 +13,27 @@ from sdpcutsel_via_nn_amd import _capi, networks, synthetic  # noqa: E402
 def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 6
-    wl = synthetic.make_workload(nb_vars=100, k=k, count=count, seed=7)
+    nv = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    wl = synthetic.make_workload(nb_vars=nv, k=k, count=count, seed=7)
     sc = _capi.Scorer(0)
     sc.set_option(_capi.OPT_TIMING, 1)
     sc.set_network(k, *networks.load_network(k))
-    sc.set_instance(100, wl["Q_arr"])
+    sc.set_instance(nv, wl["Q_arr"])
     sc.set_candidates(wl["set_inds"], wl["ks"])
     sc.set_point(wl["vars_values"])
-    for name, kv in (("mfma", _capi.KERNEL_MFMA), ("valu", _capi.KERNEL_VALU), ("simple", _capi.KERNEL_SIMPLE)):
+    variants = (("mfma", _capi.KERNEL_MFMA), ("valu", _capi.KERNEL_VALU), ("simple", _capi.KERNEL_SIMPLE))
+    if len(sys.argv) > 4:
+        variants = [v for v in variants if v[0] in sys.argv[4].split(",")]
+    for name, kv in variants:
         sc.set_option(_capi.OPT_KERNEL, kv)
         for fname, flags in (("eig", _capi.EIG), ("nn", _capi.NN), ("eig+nn", _capi.EIG | _capi.NN)):
             ts = []
             for it in range(8):
                 sc.score(flags)
                 ts.append(sc.last_timing()[0])
-            print("k=%d N=%d %-6s %-6s  median %.1f us  min %.1f us" % (k, count, name, fname, 1e3 * np.median(ts[2:]),
-                                                                      1e3 * min(ts[2:])), flush=True)
+            med = 1e3 * np.median(ts[2:])
+            print("k=%d n=%d N=%d %-6s %-6s  median %.1f us  min %.1f us  -> %.3g candidates/s" % (
+                k, nv, count, name, fname, med, 1e3 * min(ts[2:]), count / (med * 1e-6)), flush=True)
     sc.close()
 
 
