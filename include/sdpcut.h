@@ -213,6 +213,23 @@ int sdpcut_last_timing(sdpcut_handle h, double *ms, int n);
 int sdpcut_enumerate_cover(int32_t nb_vars, const uint8_t *adjacency, int32_t dim, int64_t max_out,
                            int32_t *set_inds_out, int32_t *ks_out, int64_t *count_out);
 
+/*
+ * Triangle inequalities (SURVEY.md section 8 f row 3; cut_select_qp.py:799-863).
+ * sdpcut_tri_preprocess (replaces __preprocess_triangle_ineq, :799-822): keeps the triples
+ *   i1<i2<i3 with at least two of their three edges in the sparsity graph (adjacency as in
+ *   sdpcut_enumerate_cover), lexicographic; needs sdpcut_set_instance.  sdpcut_tri_get_triples
+ *   copies them out ([T][3], density 2 or 3 per triple).
+ * sdpcut_tri_separate (replaces the scan and sort of __separate_and_add_triangle, :829-842):
+ *   at the current LP point computes the four violations of every triple, keeps those
+ *   >= 1e-7, orders them by (density desc, violation desc), ties in entry order, and returns
+ *   the first max_out as entry ids 4*triple + type with their violations.  *n_violated is the
+ *   length of the full list (the caller derives the number of cuts from it, :844-845).
+ */
+int sdpcut_tri_preprocess(sdpcut_handle h, const uint8_t *adjacency, int64_t *n_triples);
+int sdpcut_tri_get_triples(sdpcut_handle h, int32_t *triples_out, uint8_t *density_out);
+int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, double *viol_out,
+                        int64_t *n_violated, int64_t *n_written);
+
 /* Self-test hook: multiplies A[16x4] * B[4x16] with v_mfma_f64_16x16x4_f64 using the
  * fragment maps the MLP kernel assumes; C row-major [16][16]. */
 int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C);

@@ -326,3 +326,61 @@ def rank_arrays(strat, obj, lam, sel_size):
     if sel_size > 0 and N > 0 and strong / sel_size < nviol / N:
         new_strat = 1
     return order, new[second], new_strat, dict(strong=strong, violated=nviol)
+
+
+# --------------------------------------------------------------------------- triangle inequalities
+THRES_TRI_DENSE = 2             # cut_select_qp.py:31
+THRES_TRI_VIOL = 10 ** (-7)     # cut_select_qp.py:33
+TRI_CUTS_PER_ROUND_MIN = 5000   # cut_select_qp.py:39
+TRI_CUTS_PER_ROUND_MAX = 10000  # cut_select_qp.py:41
+
+
+def preprocess_triangle_ineq(nb_vars, adj):
+    """cut_select_qp.py:799-822: triples i1<i2<i3 with at least two of their three edges in the
+    sparsity graph, lexicographic.  -> (triples [T,3], density [T])."""
+    triples, dens = [], []
+    for i1 in range(nb_vars):
+        for i2 in range(i1 + 1, nb_vars):
+            for i3 in range(i2 + 1, nb_vars):
+                d = float(adj[i1, i2]) + float(adj[i1, i3]) + float(adj[i2, i3])
+                if d >= THRES_TRI_DENSE:
+                    triples.append((i1, i2, i3))
+                    dens.append(d)
+    return np.array(triples, dtype=np.int32).reshape(-1, 3), np.array(dens)
+
+
+def separate_triangle(nb_vars, triples, density, sel_size, vars_values):
+    """cut_select_qp.py:824-863 without the CPLEX call.  Returns (nb_tri_cuts, viol [T,4],
+    order = entry ids 4*t+type of the selected cuts, rows [(ind, val)], rhs)."""
+    L = nb_vars * (nb_vars + 1) // 2
+    X_vals, x_vals = list(vars_values[0:L]), list(vars_values[L:])
+    T = triples.shape[0]
+    viol = np.zeros((T, 4))
+    pos = []
+    for t in range(T):
+        s = [int(v) for v in triples[t]]
+        Xi = [nb_vars * a - a * (a + 1) // 2 + b for a, b in ((s[0], s[0]), (s[0], s[1]), (s[0], s[2]),
+                                                             (s[1], s[1]), (s[1], s[2]), (s[2], s[2]))]
+        pos.append(Xi)
+        X1, X2, X4 = X_vals[Xi[1]], X_vals[Xi[2]], X_vals[Xi[4]]
+        pt = [x_vals[i] for i in s]
+        viol[t, 0] = X1 + X2 - X4 - pt[0]
+        viol[t, 1] = X1 - X2 + X4 - pt[1]
+        viol[t, 2] = -X1 + X2 + X4 - pt[2]
+        viol[t, 3] = -X1 - X2 - X4 + sum(pt) - 1
+    entries = [(4 * t + c, density[t], viol[t, c]) for t in range(T) for c in range(4) if viol[t, c] >= THRES_TRI_VIOL]
+    entries.sort(key=lambda e: (e[1], e[2]), reverse=True)
+    nb = max(min(TRI_CUTS_PER_ROUND_MIN, int(np.floor(sel_size * len(entries)))),
+             min(TRI_CUTS_PER_ROUND_MAX, len(entries)))
+    coeffs = {0: [-1, -1, 1, 1], 1: [-1, 1, -1, 1], 2: [1, -1, -1, 1], 3: [1, 1, 1, -1, -1, -1]}
+    rows, rhs = [], []
+    for e in entries[:nb]:
+        t, c = divmod(e[0], 4)
+        Xi, s = pos[t], [int(v) for v in triples[t]]
+        if c == 3:
+            rows.append(([Xi[1], Xi[2], Xi[4], s[0] + L, s[1] + L, s[2] + L], coeffs[3]))
+            rhs.append(-1)
+        else:
+            rows.append(([Xi[1], Xi[2], Xi[4], s[c] + L], coeffs[c]))
+            rhs.append(0)
+    return nb, viol, np.array([e[0] for e in entries[:nb]], dtype=np.int64), rows, rhs

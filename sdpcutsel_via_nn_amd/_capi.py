@@ -53,6 +53,9 @@ SIGNATURES = {
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
     "sdpcut_mfma_probe": [_vp, _dp, _dp, _dp],
+    "sdpcut_tri_preprocess": [_vp, _c.POINTER(_c.c_uint8), _i64p],
+    "sdpcut_tri_get_triples": [_vp, _i32p, _c.POINTER(_c.c_uint8)],
+    "sdpcut_tri_separate": [_vp, _c.c_int64, _i64p, _dp, _i64p, _i64p],
     "sdpcut_enumerate_cover": [_c.c_int32, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i32p, _i32p, _i64p],
 }
 _RESTYPES = {"sdpcut_last_error": _c.c_char_p}
@@ -288,6 +291,32 @@ class Scorer(object):
                     n_total=int(n_total.value), new_strat=int(new_strat.value),
                     counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]),
                                   nb_positive=int(cnt[3])))
+
+    # ------------------------------------------------------------------ triangle inequalities
+    def tri_preprocess(self, adjacency):
+        """-> (triples int32 [T, 3], density uint8 [T]) kept on the device as well."""
+        adj = np.ascontiguousarray(np.asarray(adjacency) != 0, dtype=np.uint8)
+        if adj.shape != (self.nb_vars, self.nb_vars):
+            raise ValueError("adjacency must be [n, n]")
+        T = _c.c_int64(0)
+        self._check(self._lib.sdpcut_tri_preprocess(self._h, adj.ctypes.data_as(_c.POINTER(_c.c_uint8)),
+                                                    ctypes.byref(T)))
+        tri = np.empty((max(T.value, 1), 3), dtype=np.int32)
+        dens = np.empty(max(T.value, 1), dtype=np.uint8)
+        self._check(self._lib.sdpcut_tri_get_triples(self._h, _ptr(tri, _i32p),
+                                                     dens.ctypes.data_as(_c.POINTER(_c.c_uint8))))
+        self.n_tri = int(T.value)
+        return tri[:T.value], dens[:T.value]
+
+    def tri_separate(self, max_out):
+        """-> (entry ids 4*triple+type int64[w], violations float64[w], n_violated)"""
+        cap = max(0, min(int(max_out), 4 * getattr(self, "n_tri", 0)))
+        ent = np.empty(max(cap, 1), dtype=np.int64)
+        vio = np.empty(max(cap, 1))
+        nv, nw = _c.c_int64(0), _c.c_int64(0)
+        self._check(self._lib.sdpcut_tri_separate(self._h, cap, _ptr(ent, _i64p), _ptr(vio, _dp), ctypes.byref(nv),
+                                                  ctypes.byref(nw)))
+        return ent[:nw.value], vio[:nw.value], int(nv.value)
 
     def eig_batch(self, k, x_rho, X_rho, want_vectors=False):
         x_rho, X_rho = _f64(x_rho), _f64(X_rho)

@@ -79,6 +79,7 @@ int sdpcut_destroy(sdpcut_handle h)
     free_candidates(h);
     free_rank_ws(h);
     free_topk_ws(h);
+    (void)hipFree(h->d_tri); (void)hipFree(h->d_tri_dense3);
     if (h->pinned) (void)hipHostFree(h->pinned);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
@@ -652,6 +653,51 @@ int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs,
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, d_out, c * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SDPCUT_OK;
+}
+
+int sdpcut_tri_preprocess(sdpcut_handle h, const uint8_t *adjacency, int64_t *n_triples)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
+    if (!adjacency) return sdpcut_fail(h, SDPCUT_EINVAL, "adjacency is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return tri_preprocess(h, adjacency, n_triples);
+}
+
+int sdpcut_tri_get_triples(sdpcut_handle h, int32_t *triples_out, uint8_t *density_out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (h->n_tri > 0 && !triples_out) return sdpcut_fail(h, SDPCUT_EINVAL, "triples_out is NULL");
+    if (h->n_tri > 0) std::memcpy(triples_out, h->tri_host.data(), (size_t)h->n_tri * 3 * sizeof(int32_t));
+    if (density_out)
+        for (int64_t t = 0; t < h->n_tri; ++t) density_out[t] = h->tri_dense_host[t] ? 3 : 2;
+    return SDPCUT_OK;
+}
+
+int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, double *viol_out, int64_t *n_violated,
+                        int64_t *n_written)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
+    if (max_out < 0 || (max_out > 0 && (!entry_out || !viol_out)) || !n_violated || !n_written)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad tri_separate arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int64_t cap = max_out < 4 * h->n_tri ? max_out : 4 * h->n_tri;
+    int rc = ensure_stage(h, (size_t)(cap < 1 ? 1 : cap) * 16);
+    if (rc) return rc;
+    int64_t *d_e = (int64_t *)h->d_stage;
+    double *d_v = (double *)((char *)h->d_stage + (size_t)(cap < 1 ? 1 : cap) * 8);
+    int64_t w = 0;
+    rc = tri_separate(h, cap, d_e, d_v, n_violated, &w);
+    if (rc) return rc;
+    if (w > 0) {
+        HIP_TRY(h, hipMemcpyAsync(entry_out, d_e, w * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(viol_out, d_v, w * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *n_written = w;
     return SDPCUT_OK;
 }
 

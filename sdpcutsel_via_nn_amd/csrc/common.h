@@ -81,6 +81,12 @@ struct sdpcut_ctx {
     void *d_topk_ws = nullptr;
     uint64_t *d_sel_key = nullptr;
     uint32_t *d_sel_idx = nullptr;
+    // triangle inequalities (tri.hip)
+    int32_t *d_tri = nullptr;          // [T][3]
+    uint8_t *d_tri_dense3 = nullptr;   // [T] density == 3
+    int64_t n_tri = 0;
+    std::vector<int32_t> tri_host;
+    std::vector<uint8_t> tri_dense_host;
     // small staging
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -122,6 +128,11 @@ int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_ou
                       double *d_score_out, const int64_t **d_c4);
 int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[4],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out);
+
+// tri.hip
+int tri_preprocess(sdpcut_ctx *h, const uint8_t *adjacency, int64_t *n_triples);
+int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d_viol_out, int64_t *n_violated,
+                 int64_t *n_written);
 
 // topk.hip
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,

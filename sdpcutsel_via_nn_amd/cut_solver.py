@@ -375,6 +375,62 @@ class GpuCutSelectionMixin(object):
             self._gpu_aux_scorer = _capi.Scorer(self._gpu_device)
         return self._gpu_aux_scorer
 
+    # ------------------------------------------------------------------ triangle inequalities (8 f row 3)
+    _THRES_TRI_VIOL = 10 ** (-7)
+    _TRI_CUTS_PER_ROUND_MIN = 5000
+    _TRI_CUTS_PER_ROUND_MAX = 10000
+
+    def _gpu_dense_adj(self):
+        """``self._Q_adj`` as a dense boolean array (the reference keeps a cvxopt spmatrix)."""
+        adj = self._Q_adj
+        if hasattr(adj, "I") and hasattr(adj, "J"):            # cvxopt.spmatrix
+            out = np.zeros((self._nb_vars, self._nb_vars), dtype=bool)
+            out[np.array(list(adj.I), dtype=int), np.array(list(adj.J), dtype=int)] = True
+            return out
+        if hasattr(adj, "a"):                                   # dense stand-in used by make_golden.py
+            return np.asarray(adj.a) != 0
+        return np.asarray(adj) != 0
+
+    def _preprocess_triangle_ineq(self):
+        """Triples to consider as triangle inequalities (cut_select_qp.py:799-822); the list
+        lives on the device, the host keeps a copy for building the rows."""
+        sc = _capi.Scorer(self._gpu_device)
+        sc.set_instance(self._nb_vars, np.asarray(self._Q_arr, dtype=np.float64))
+        self._gpu_tri = sc
+        self._gpu_tri_triples, self._gpu_tri_density = sc.tri_preprocess(self._gpu_dense_adj())
+        # the reference's bookkeeping lists, for code that only looks at their length
+        self._idx_list_tri = self._gpu_tri_triples
+        self._rank_list_tri = None
+
+    def _separate_and_add_triangle(self, sel_size, vars_values):
+        """Separate the violated triangle inequalities at the current point, rank them by
+        (density, violation) and append the selected ones (cut_select_qp.py:824-863)."""
+        sc, tri, L, n = self._gpu_tri, self._gpu_tri_triples, self._nb_lifted, self._nb_vars
+        sc.set_point(np.ascontiguousarray(vars_values, dtype=np.float64))
+        ent, vio, nb_viol = sc.tri_separate(self._TRI_CUTS_PER_ROUND_MAX)
+        nb_tri_cuts = max(min(self._TRI_CUTS_PER_ROUND_MIN, int(np.floor(sel_size * nb_viol))),
+                          min(self._TRI_CUTS_PER_ROUND_MAX, nb_viol))                       # :844-845
+        pair = self._sparse_pair or _default_sparse_pair()
+        coeffs = {0: [-1, -1, 1, 1], 1: [-1, 1, -1, 1], 2: [1, -1, -1, 1], 3: [1, 1, 1, -1, -1, -1]}
+        rows, rhs = [], []
+        for e in ent[:nb_tri_cuts]:
+            t, c = divmod(int(e), 4)
+            a, b, d = (int(v) for v in tri[t])
+            ra, rb = n * a - a * (a + 1) // 2, n * b - b * (b + 1) // 2
+            X = [ra + b, ra + d, rb + d]                        # Xarr_inds[1], [2], [4]
+            if c == 3:
+                rows.append(pair(ind=X + [a + L, b + L, d + L], val=coeffs[3]))
+                rhs.append(-1)
+            else:
+                rows.append(pair(ind=X + [(a, b, d)[c] + L], val=coeffs[c]))
+                rhs.append(0)
+        self._my_prob.linear_constraints.add(lin_expr=rows, rhs=rhs, senses=["G"] * len(rows))
+        return len(rows)
+
+    # the reference reaches these two through name-mangled private names inside class CutSolver
+    _CutSolver__preprocess_triangle_ineq = _preprocess_triangle_ineq
+    _CutSolver__separate_and_add_triangle = _separate_and_add_triangle
+
     # ------------------------------------------------------------------ a6 eigen helper
     def _get_eigendecomp(self, dim_subpr, curr_pt, X_slice, ev_yes):
         """Eigen-decomposition of [[1, x^T],[x, X]] (cut_select_qp.py:788-797): ascending
@@ -429,12 +485,12 @@ class CutSolver(GpuCutSelectionMixin):
     _CONVERGENCE_TOL = 10 ** (-3)         # cut_select_qp.py:29
 
     def cut_select_algo(self, filename, dim, sel_size, strat=2, nb_rounds_cuts=20, term_on=False,
-                        strong_only=False):
+                        triangle_on=False, strong_only=False):
         """Algorithm 1 on a BoxQP ``.in`` file without CPLEX: the call sequence of
         cut_select_qp.py:73-221 (parse -> vertex cover -> McCormick relaxation -> rounds of
         [select, generate, re-solve]) with scipy's HiGHS as LP solver, our C++ cover
-        enumeration and the GPU-backed selection methods.  Triangle cuts, dense cuts
-        (strat 0), exact-SDP strategies and chordal extensions are out of scope.
+        enumeration and the GPU-backed selection / triangle separation.  Dense cuts (strat 0),
+        exact-SDP strategies and chordal extensions are out of scope.
         Returns the reference's default tuple
         (bounds per round, total time, round times, separation times, nb cuts per round, [], nb candidates)."""
         from timeit import default_timer as timer
@@ -443,17 +499,19 @@ class CutSolver(GpuCutSelectionMixin):
         assert 0 < sel_size, "The selection size must be a % or number (of cuts) >0!"
         assert dim <= 5, "Keep SDP vertex cover low-dimensional (<=5)!"
         time_begin = timer()
-        nbs_sdp_cuts, curr_obj_vals, round_times, sep_times = [0], [], [], []
+        nbs_sdp_cuts, nbs_tri_cuts, curr_obj_vals, round_times, sep_times = [0], [], [], [], []
         self._dim = dim
         if strat in (2, 4):
             self._load_neural_nets()
         inst = harness.parse_boxqp(filename)
         self._nb_vars, self._nb_lifted, self._Q_arr = inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
+        self._Q_adj = inst["adj"]
         self._my_prob = my_prob = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
         set_inds, ks, nb_subprobs = _capi.enumerate_cover(inst["adj"], dim, max_subs=self._THRES_MAX_SUBS)
         if nb_subprobs >= self._THRES_MAX_SUBS or nb_rounds_cuts == 0:          # :117-120
             return [0, 0], timer() - time_begin, 0, 0, [0], 0, nb_subprobs
         self._agg_list = AggArrays(set_inds, ks, self._nb_vars, self._Q_arr)
+        sel_size_frac = sel_size
         sel_size = self.selection_size(sel_size, nb_subprobs)
         t0 = timer()
         my_prob.linear_constraints.add(*harness.mccormick_rows(self._nb_vars, inst["adj"]))
@@ -463,6 +521,8 @@ class CutSolver(GpuCutSelectionMixin):
         round_times.append(timer() - t0 + sep_times[0])
         curr_obj_vals.append(my_prob.get_objective_value())
         vars_values = np.array(my_prob.get_values())
+        if triangle_on:
+            self._preprocess_triangle_ineq()                                       # :140-141
         strat_change = strat
         for cut_round in range(1, nb_rounds_cuts + 1):
             if (term_on and len(curr_obj_vals) >= 3 and curr_obj_vals[-1] != curr_obj_vals[0] and
@@ -477,6 +537,7 @@ class CutSolver(GpuCutSelectionMixin):
                 rank_list = self._sel_eigcut_by_ordering_on_measure(strat, vars_values, cut_round)
             nbs_sdp_cuts.append(self._gen_eigcuts_selected(strat, sel_size, rank_list, strong_only=strong_only,
                                                            vars_values=vars_values))
+            nbs_tri_cuts.append(self._separate_and_add_triangle(sel_size_frac, vars_values) if triangle_on else 0)
             sep_times.append(timer() - t_sep)
             strat = strat_change                                                   # :188
             t0 = timer()
@@ -484,8 +545,8 @@ class CutSolver(GpuCutSelectionMixin):
             round_times.append(timer() - t0 + sep_times[-1])
             curr_obj_vals.append(my_prob.get_objective_value())
             vars_values = np.array(my_prob.get_values()).astype(float)
-        return ([-obj for obj in curr_obj_vals], timer() - time_begin, round_times, sep_times, nbs_sdp_cuts, [],
-                nb_subprobs)
+        return ([-obj for obj in curr_obj_vals], timer() - time_begin, round_times, sep_times, nbs_sdp_cuts,
+                nbs_tri_cuts, nb_subprobs)
 
 
 class CutSolverQCQP(CutSolver):

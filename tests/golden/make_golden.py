@@ -291,8 +291,50 @@ def golden_fig8():
     print("fig8_round1.csv", len(rows) - 1, "rows")
 
 
+
+
+def golden_triangles(qp):
+    """Source 2, triangle inequalities (cut_select_qp.py:799-863): the reference's own
+    pre-processing and separation on two instances at a random McCormick-feasible point and at
+    the McCormick optimum."""
+    out = {}
+    rng = np.random.default_rng(17)
+    for name in ("spar020-100-1", "spar040-030-1"):
+        cs = qp.CutSolver()
+        cs._CutSolver__parse_boxqp_into_cplex(name)
+        n = cs._nb_vars
+        inst = harness.parse_boxqp(os.path.join(REF, "boxqp_instances", name + ".in"))
+        cs._CutSolver__preprocess_triangle_ineq()
+        tag = name.replace("-", "_")
+        out[tag + "_nb_vars"] = np.int64(n)
+        out[tag + "_adj"] = (cs._Q_adj.a != 0)
+        out[tag + "_triples"] = np.array([t[1] for t in cs._idx_list_tri], dtype=np.int32).reshape(-1, 3)
+        out[tag + "_density"] = np.array([e[2] for e in cs._rank_list_tri], dtype=np.float64)
+        pts = {"rnd": harness.random_mccormick_point(n, rng),
+               "mck": mccormick_optimum(n, cs._Q_adj.a != 0, inst["Q_arr"], inst["c"])}
+        for pname, vv in pts.items():
+            for sel in (0.1, 0.5):
+                cs._my_prob = _Recorder()
+                nb = cs._CutSolver__separate_and_add_triangle(sel, vv)
+                viol = np.array([e[3] for e in cs._rank_list_tri], dtype=np.float64)
+                ptr, ind, val, rhs = pack_rows(cs._my_prob)
+                q = "%s_%s_%s" % (tag, pname, str(sel).replace(".", "p"))
+                out[q + "_vars"] = vv
+                out[q + "_viol"] = viol
+                out[q + "_nb"] = np.int64(nb)
+                out[q + "_row_ptr"], out[q + "_row_ind"], out[q + "_row_val"], out[q + "_rhs"] = ptr, ind, val, rhs
+        print(tag, "triples", len(cs._idx_list_tri))
+    np.savez_compressed(os.path.join(HERE, "inst_tri.npz"), **out)
+
+
 if __name__ == "__main__":
-    golden_fig8()
-    golden_random()
+    only = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if only in ("all", "fig8"):
+        golden_fig8()
+    if only in ("all", "random"):
+        golden_random()
     qp, qcqp = import_reference()
-    golden_instances(qp, qcqp)
+    if only in ("all", "instances"):
+        golden_instances(qp, qcqp)
+    if only in ("all", "tri"):
+        golden_triangles(qp)
