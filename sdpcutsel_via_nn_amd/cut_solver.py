@@ -583,3 +583,40 @@ class CutSolverQCQP(CutSolver):
         nb_b = self._gen_eigcuts_selected(strat_old, nb_cuts_combined, comb_obj[0:nb_cuts_combined],
                                           vars_values=vars_values)
         return strat, rank_list, nb_a + nb_b, nb_opt_cuts
+
+    def cut_select_algo(self, filename, dim, sel_size=0.1, strat=2, nb_rounds_cuts=20):
+        """Algorithm 1 adapted to QCQP on an OSiL file without CPLEX: the call sequence of
+        cut_select_qcqp.py:16-113 (parse -> McCormick on the objective's edges -> LP -> two
+        covers -> rounds) with HiGHS, our cover enumeration and the GPU-backed selection.
+        Returns (objective value per round, sel_size, nb cuts per round, nb optimality cuts per round)."""
+        from . import harness
+        assert strat in (1, 2, 4, 5), "strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random"
+        assert 0 < sel_size, "The selection size must be a % or number (of cuts) >0!"
+        assert dim <= 5, "Keep SDP vertex cover low-dimensional (<=5)!"
+        self._dim = dim
+        inst = harness.parse_osil(filename)
+        self._nb_vars, self._nb_lifted, self._Q_arr = inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
+        self._Q_adj, self._Q_adj_cons = inst["adj"], inst["adj_cons"]
+        self._my_prob = my_prob = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
+        my_prob.linear_constraints.add(inst["rows"], inst["rhs"], inst["senses"])
+        my_prob.linear_constraints.add(*harness.mccormick_rows(self._nb_vars, inst["adj"]))      # :36
+        self._load_neural_nets()
+        my_prob.solve()
+        obj_values_rounds = [my_prob.get_objective_value()]
+        vars_values = np.array(my_prob.get_values())
+        (So, ko), (Sc, kc) = harness.qcqp_covers(inst, dim, _capi.enumerate_cover)               # :50, :314-334
+        agg_list = AggArrays(So, ko, self._nb_vars, self._Q_arr)
+        agg_list_cons = AggArrays(Sc, kc, self._nb_vars, self._Q_arr)
+        self._agg_list = agg_list
+        sel_size = self.selection_size(sel_size, len(agg_list), minimum=1)                       # :55-58
+        nbs_opt_cuts = [0] * (nb_rounds_cuts + 1)
+        nbs_sdp_cuts = [0]
+        for cut_round in range(1, nb_rounds_cuts + 1):
+            strat, rank_list, nb_sdp_cuts, nb_opt = self.select_and_generate_round(
+                strat, vars_values, cut_round, sel_size, agg_list, agg_list_cons)
+            nbs_opt_cuts[cut_round] = nb_opt
+            nbs_sdp_cuts.append(nb_sdp_cuts)
+            my_prob.solve()
+            obj_values_rounds.append(my_prob.get_objective_value())
+            vars_values = np.array(my_prob.get_values()).astype(float)
+        return obj_values_rounds, sel_size, nbs_sdp_cuts, nbs_opt_cuts

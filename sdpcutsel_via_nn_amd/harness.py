@@ -55,18 +55,20 @@ class LinearRelaxation(object):
         from scipy.sparse import csr_matrix
         st = self.linear_constraints
         nv = self.obj.shape[0]
-        data, cols, ptr = [], [], [0]
-        sign = []
-        for row, sense in zip(st.rows, st.senses):
+        blocks = {"U": ([], [], [0], []), "E": ([], [], [0], [])}       # data, cols, ptr, rhs
+        for row, sense, rhs in zip(st.rows, st.senses, st.rhs):
+            assert sense in ("G", "L", "E"), sense
             s = -1.0 if sense == "G" else 1.0
-            assert sense in ("G", "L"), "harness supports inequality rows only"
+            data, cols, ptr, b = blocks["E" if sense == "E" else "U"]
             data.extend(s * np.asarray(row.val, dtype=np.float64))
             cols.extend(row.ind)
             ptr.append(len(cols))
-            sign.append(s)
-        A = csr_matrix((data, cols, ptr), shape=(len(st.rows), nv))
-        b = np.asarray(st.rhs, dtype=np.float64) * np.asarray(sign)
-        res = linprog(self.obj, A_ub=A, b_ub=b, bounds=(0, 1), method="highs-ds")
+            b.append(s * rhs)
+        mats = {}
+        for key, (data, cols, ptr, b) in blocks.items():
+            mats[key] = (csr_matrix((data, cols, ptr), shape=(len(b), nv)), np.asarray(b, dtype=np.float64)) if b else (None, None)
+        res = linprog(self.obj, A_ub=mats["U"][0], b_ub=mats["U"][1], A_eq=mats["E"][0], b_eq=mats["E"][1],
+                      bounds=(0, 1), method="highs-ds")
         if res.status != 0:
             raise RuntimeError("HiGHS: " + res.message)
         self._values, self._objval = res.x, res.fun
@@ -132,3 +134,84 @@ def random_mccormick_point(nb_vars, rng):
     hi = np.minimum(x[iu[0]], x[iu[1]])
     X = lo + (hi - lo) * rng.uniform(0.0, 1.0, lo.shape[0])
     return np.concatenate([X, x])
+
+
+def parse_osil(path):
+    """QCQP instance in OSiL (cut_select_qcqp.py:115-312, data side only).  Returns
+    dict(nb_vars, nb_lifted, c, Q_arr, adj, adj_cons, rows, rhs, senses): the objective's packed
+    coefficient table and adjacency (:247-256), the adjacency of objective + all constraints, and
+    the linearised constraints over [X packed | x] (:283-311; quadratic terms lifted to X_ij)."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(path).getroot()
+    for el in root.iter():
+        el.tag = el.tag.split("}", 1)[-1]
+    data = root.find("instanceData")
+    n = int(data.find("variables").attrib["numberOfVariables"])
+    L = n * (n + 1) // 2
+    obj = data.find("objectives/obj")
+    c = np.zeros(n)
+    if obj.attrib.get("maxOrMin") == "min":
+        for co in obj.findall("coef"):
+            c[int(co.attrib["idx"])] = float(co.text)
+
+    def expand(parent, tag, as_int, n_out, start_rule=False):
+        """<el mult= incr=>v</el> run-length lists of OSiL."""
+        out = []
+        for el in parent.find(tag).findall("el"):
+            mult, incr = int(el.attrib.get("mult", 1)), int(el.attrib.get("incr", 0 if start_rule or not as_int else 1))
+            v = int(el.text) if as_int else float(el.text)
+            if "incr" not in el.attrib and as_int and not start_rule:
+                incr = 1
+            out.extend([v + k * incr for k in range(mult)] if as_int else [v] * mult)
+        return out[:n_out] if n_out is not None else out
+
+    cons = data.find("constraints")
+    nb_cons = int(cons.attrib["numberOfConstraints"]) if cons is not None else 0
+    sgn_rhs = []
+    if cons is not None:
+        for con in cons.findall("con"):
+            lb, ub = con.attrib.get("lb"), con.attrib.get("ub")
+            sgn_rhs.append(("E", float(lb)) if lb and ub else (("G", float(lb)) if lb else ("L", float(ub))))
+    col_idx, col_val, starts = [], [], [0] * (nb_cons + 1)
+    lin = data.find("linearConstraintCoefficients")
+    if lin is not None and nb_cons:
+        nvals = int(lin.attrib["numberOfValues"])
+        col_idx = expand(lin, "colIdx", True, nvals)
+        col_val = expand(lin, "value", False, nvals)
+        starts = expand(lin, "start", True, nb_cons + 1, start_rule=True)
+    qterms = []
+    quad = data.find("quadraticCoefficients")
+    if quad is not None:
+        for q in quad.findall("qTerm"):
+            qterms.append((int(q.attrib["idx"]), int(q.attrib["idxOne"]), int(q.attrib["idxTwo"]), float(q.attrib["coef"])))
+    Q = np.zeros((n, n))
+    adj = np.zeros((n, n), dtype=bool)
+    adj_cons = np.zeros((n, n), dtype=bool)
+    for k, i, j, v in qterms:
+        if k == -1:
+            adj[i, j] = adj[j, i] = True
+            Q[i, j] = Q[j, i] = v
+        adj_cons[i, j] = adj_cons[j, i] = True
+    rows, rhs, senses = [], [], []
+    for ci in range(nb_cons):
+        ind = [n * i - i * (i + 1) // 2 + j for k, i, j, v in qterms if k == ci]
+        val = [v for k, i, j, v in qterms if k == ci]
+        for t in range(starts[ci], starts[ci + 1]):
+            ind.append(int(col_idx[t]) + L)
+            val.append(col_val[t])
+        rows.append(SparsePair(ind, val))
+        senses.append(sgn_rhs[ci][0])
+        rhs.append(sgn_rhs[ci][1])
+    return dict(nb_vars=n, nb_lifted=L, c=c, Q_arr=Q[np.triu_indices(n)], adj=adj, adj_cons=adj_cons, rows=rows, rhs=rhs,
+                senses=senses)
+
+
+def qcqp_covers(inst, dim, enumerate_cover):
+    """Objective / constraint covers of cut_select_qcqp.py:314-334: the sub-problems of the
+    objective+constraints graph that also belong to the objective-only cover, and the rest
+    (both in the order of the objective+constraints enumeration).  -> two (set_inds, ks) pairs."""
+    So, ko, _ = enumerate_cover(inst["adj"], dim)
+    Sc, kc, _ = enumerate_cover(inst["adj_cons"], dim)
+    in_obj = {tuple(int(v) for v in So[i, :ko[i]]) for i in range(ko.shape[0])}
+    mask = np.array([tuple(int(v) for v in Sc[i, :kc[i]]) in in_obj for i in range(kc.shape[0])], dtype=bool)
+    return (Sc[mask], kc[mask]), (Sc[~mask], kc[~mask])

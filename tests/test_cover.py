@@ -85,3 +85,22 @@ def test_cover_argument_errors():
         _capi.enumerate_cover(np.ones((4, 5)), 3)
     S, ks, N = _capi.enumerate_cover(np.zeros((6, 6)), 3)
     assert N == 0 and S.shape == (0, 5)
+
+
+def test_osil_parser_and_qcqp_covers(golden_qcqp):
+    """OSiL data side (cut_select_qcqp.py:229-259) and the two covers of :314-334 against what the
+    reference itself produced on q_20_4_25_1 (tests/golden/inst_qcqp.npz)."""
+    from sdpcutsel_via_nn_amd import _capi, harness
+    g = golden_qcqp
+    inst = harness.parse_osil(os.path.join(GOLDEN, "instances", "q_20_4_25_1.osil"))
+    assert inst["nb_vars"] == int(g["nb_vars"]) and np.array_equal(inst["Q_arr"], g["Q_arr"])
+    assert inst["senses"] == ["L"] * 4 and inst["rhs"] == [49.695, 18.723, 56.565, 28.634]
+    assert [len(r.ind) for r in inst["rows"]] == [52 + 20, 52 + 20, 52 + 20, 52 + 20]
+    (So, ko), (Sc, kc) = harness.qcqp_covers(inst, 3, _capi.enumerate_cover)
+    assert np.array_equal(So, g["obj_set_inds"]) and np.array_equal(ko, g["obj_k"])
+    assert np.array_equal(Sc, g["cons_set_inds"]) and np.array_equal(kc, g["cons_k"])
+    lp = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
+    lp.linear_constraints.add(inst["rows"], inst["rhs"], inst["senses"])
+    lp.linear_constraints.add(lin_expr=[harness.SparsePair([210], [1.0])], rhs=[0.5], senses=["E"])   # equality rows
+    lp.solve()
+    assert abs(lp.get_values()[210] - 0.5) < 1e-9

@@ -73,3 +73,23 @@ def test_config3_slice_spar125_dim3_two_rounds():
     assert nb_cuts == [0, 5000]                                      # published r1 cut count (cap :37)
     assert bounds[1] < bounds[0]
     assert sep_times[1] < 1.0        # reference: 2.5 s separation for this round (data_all_boxqp_4rounds.csv:100)
+
+
+@pytest.mark.parametrize("strat", [4, 2, 1])
+def test_qcqp_rounds_q_20_4_25_1(strat):
+    """QCQP path end to end (cut_select_qcqp.py:16-113 call sequence): OSiL -> LP -> two covers ->
+    rounds of [objective cover by `strat`, constraint cover by feasibility, concatenate, generate]."""
+    import sdpcutsel_via_nn_amd as pkg
+    cs = pkg.CutSolverQCQP()
+    path = os.path.join(GOLDEN, "instances", "q_20_4_25_1.osil")
+    objs, sel_size, nb_cuts, nb_opt = cs.cut_select_algo(path, 3, sel_size=0.5, strat=strat, nb_rounds_cuts=4)
+    assert sel_size == 9                                  # floor(0.5 * 19 objective sub-problems)
+    assert len(objs) == 5 and all(b >= a - 1e-9 for a, b in zip(objs, objs[1:]))     # the bound only tightens
+    assert nb_cuts[0] == 0 and all(0 <= c <= sel_size for c in nb_cuts[1:])
+    if strat == 1:
+        # the McCormick optimum of this instance is integral: no objective sub-problem is violated, 312 of the
+        # 491 constraint-only ones are.  Only the feasibility strategy lists violated entries alone, so only there
+        # does the concatenation (cut_select_qcqp.py:79) reach the constraint cover within sel_size entries.
+        assert nb_cuts[1] == sel_size and objs[-1] >= objs[0]
+    else:
+        assert nb_cuts[1] == 0            # faithful to the reference: 19 unviolated objective entries fill the quota
