@@ -39,6 +39,16 @@ def _default_sparse_pair():
         return SparsePair
 
 
+def rows_to_csr(coef, cols, ks):
+    """Padded cut rows (stride SDPCUT_ROW_LD, row c has k_c(k_c+3)/2 live entries) -> CSR
+    (indptr int64 [R+1], indices int64, values float64)."""
+    ks = np.asarray(ks, dtype=np.int64)
+    lens = ks * (ks + 3) // 2
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    live = np.arange(coef.shape[1])[None, :] < lens[:, None]
+    return indptr, np.ascontiguousarray(cols[live], dtype=np.int64), np.ascontiguousarray(coef[live], dtype=np.float64)
+
+
 class FeasEntry(tuple):
     """``(set_inds, -eigval, Xarr_inds, dim_act)`` of cut_select_qp.py:649, remembering which
     candidate it came from so that cut generation needs no search."""
@@ -326,6 +336,13 @@ class GpuCutSelectionMixin(object):
                 self._gpu_point(b, vv, 0)
                 lam, coef, rhs, cols, ks = b.scorer.cut_rows(idx - b.scorer.base)
                 keep = np.nonzero(lam < _THRES_NEG_EIGVAL)[0]          # :743
+                store = self._my_prob.linear_constraints
+                if hasattr(store, "add_csr"):
+                    # batched assembly (SURVEY 8 f row 4): the padded device rows become one CSR
+                    # block with array operations, no Python object per cut
+                    indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
+                    store.add_csr(indptr, ind, val, rhs[keep], "G")
+                    return int(keep.size)
                 for c in keep:
                     w = int(ks[c]) * (int(ks[c]) + 3) // 2
                     rows.append(pair(ind=cols[c, :w].tolist(), val=coef[c, :w].tolist()))

@@ -26,18 +26,62 @@ class SparsePair(object):
 
 
 class _RowStore(object):
+    """Rows of the LP.  ``add`` takes the reference's per-row objects (cut_select_qp.py:754);
+    ``add_csr`` takes a whole block of rows as CSR arrays (batched cut assembly, SURVEY 8 f
+    row 4).  ``rows`` materialises SparsePair objects only if somebody asks for them."""
+
     def __init__(self):
-        self.rows, self.rhs, self.senses = [], [], []
+        self._blocks, self.rhs, self.senses = [], [], []
+        self._n = 0
 
     def add(self, lin_expr=(), rhs=(), senses=()):
-        start = len(self.rows)
-        self.rows.extend(lin_expr)
+        start = self._n
+        lin_expr = list(lin_expr)
+        self._blocks.append(("rows", lin_expr))
+        self._n += len(lin_expr)
         self.rhs.extend(rhs)
         self.senses.extend(senses)
-        return range(start, len(self.rows))
+        return range(start, self._n)
+
+    def add_csr(self, indptr, indices, values, rhs, sense):
+        start, r = self._n, len(indptr) - 1
+        self._blocks.append(("csr", np.asarray(indptr), np.asarray(indices), np.asarray(values)))
+        self._n += r
+        self.rhs.extend(float(v) for v in rhs)
+        self.senses.extend([sense] * r)
+        return range(start, self._n)
 
     def get_num(self):
-        return len(self.rows)
+        return self._n
+
+    @property
+    def rows(self):
+        out = []
+        for b in self._blocks:
+            if b[0] == "rows":
+                out.extend(b[1])
+            else:
+                _, ptr, ind, val = b
+                out.extend(SparsePair(ind[ptr[r]:ptr[r + 1]].tolist(), val[ptr[r]:ptr[r + 1]].tolist())
+                           for r in range(len(ptr) - 1))
+        return out
+
+    def csr_parts(self):
+        """(data, cols, lengths) of all rows in order, as arrays."""
+        data, cols, lens = [], [], []
+        for b in self._blocks:
+            if b[0] == "rows":
+                for row in b[1]:
+                    data.append(np.asarray(row.val, dtype=np.float64))
+                    cols.append(np.asarray(row.ind, dtype=np.int64))
+                    lens.append(len(row.ind))
+            else:
+                _, ptr, ind, val = b
+                data.append(val)
+                cols.append(ind)
+                lens.extend(np.diff(ptr).tolist())
+        cat = (lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt))
+        return cat(data, np.float64), cat(cols, np.int64), np.asarray(lens, dtype=np.int64)
 
 
 class LinearRelaxation(object):
@@ -55,20 +99,17 @@ class LinearRelaxation(object):
         from scipy.sparse import csr_matrix
         st = self.linear_constraints
         nv = self.obj.shape[0]
-        blocks = {"U": ([], [], [0], []), "E": ([], [], [0], [])}       # data, cols, ptr, rhs
-        for row, sense, rhs in zip(st.rows, st.senses, st.rhs):
-            assert sense in ("G", "L", "E"), sense
-            s = -1.0 if sense == "G" else 1.0
-            data, cols, ptr, b = blocks["E" if sense == "E" else "U"]
-            data.extend(s * np.asarray(row.val, dtype=np.float64))
-            cols.extend(row.ind)
-            ptr.append(len(cols))
-            b.append(s * rhs)
-        mats = {}
-        for key, (data, cols, ptr, b) in blocks.items():
-            mats[key] = (csr_matrix((data, cols, ptr), shape=(len(b), nv)), np.asarray(b, dtype=np.float64)) if b else (None, None)
-        res = linprog(self.obj, A_ub=mats["U"][0], b_ub=mats["U"][1], A_eq=mats["E"][0], b_eq=mats["E"][1],
-                      bounds=(0, 1), method="highs-ds")
+        data, cols, lens = st.csr_parts()
+        senses = np.asarray(st.senses)
+        assert np.all(np.isin(senses, ["G", "L", "E"]))
+        sign = np.where(senses == "G", -1.0, 1.0)
+        rhs = np.asarray(st.rhs, dtype=np.float64) * sign
+        ptr = np.concatenate([[0], np.cumsum(lens)])
+        A = csr_matrix((data * np.repeat(sign, lens), cols, ptr), shape=(lens.shape[0], nv))
+        eq = senses == "E"
+        A_ub, b_ub = (A[~eq], rhs[~eq]) if (~eq).any() else (None, None)
+        A_eq, b_eq = (A[eq], rhs[eq]) if eq.any() else (None, None)
+        res = linprog(self.obj, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=(0, 1), method="highs-ds")
         if res.status != 0:
             raise RuntimeError("HiGHS: " + res.message)
         self._values, self._objval = res.x, res.fun
