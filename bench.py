@@ -116,11 +116,10 @@ def main():
             # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> one D2H
             res = rows = sc.select_round(4, SEL)
         else:
+            # score the shard -> packed head record -> ONE all-gather (RCCL) -> replicated merge ->
+            # each rank generates the rows of its own candidates -> one D2H, one host sync
             sc.score(_capi.EIG | _capi.NN)
-            res = sel.select(4, SEL)                     # per-shard heads, RCCL all-gather, replicated merge
-            ids = res["ids"].cpu().numpy()
-            mine = ids[(ids >= lo) & (ids < hi)] - lo
-            rows = sc.cut_rows(mine)                     # each rank generates the rows of its own candidates
+            res = rows = sel.select_round(4, SEL)
         kernel_ms.append(sc.last_timing()[0])
         return res, rows
 

@@ -186,6 +186,30 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
                         int32_t *new_strat, int64_t *counters);
 
 /*
+ * The same round over candidate shards (one handle per GPU, SURVEY 8 e): the two device-side
+ * halves around the single all-gather the caller performs (torch.distributed / RCCL).
+ *
+ * sdpcut_shard_head_device: enqueue, WITHOUT host synchronisation, this shard's head of the
+ * ranking (strat 1, 2 or SDPCUT_PART_STRONG) into one packed device record of 8 + 2*count
+ * int64 words
+ *     [list length, nb_violated, nb_positive, entries written, 0, 0, 0, 0 |
+ *      count scores (fp64 bits) | count GLOBAL ids]
+ * padded with (-inf, INT64_MAX); 1 <= count <= 8192.
+ *
+ * sdpcut_shard_finish_round: d_allrec holds the `world` records in rank order.  Merges them
+ * by (score descending, id ascending) -- the order of the reference's stable sort on one list
+ * (cut_select_qp.py:601, :653) --, keeps the first sel_size entries and produces the eigen-cut
+ * rows of those that belong to THIS shard (the others: ks = 0, lam_min = NaN); one transfer,
+ * one synchronisation.  headers_out [world][8] are the record headers (the caller sums them);
+ * entries beyond the summed list length are pads.  Other outputs as in sdpcut_select_round.
+ */
+int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t count, void *d_record);
+int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count,
+                              const void *d_allrec, int64_t sel_size, int32_t coef_ld,
+                              int64_t *headers_out, int64_t *idx_out, double *score_out,
+                              double *lam_min, double *coef, double *rhs, int32_t *ks);
+
+/*
  * Batched twin of _get_eigendecomp (cut_select_qp.py:788-797) for explicit sub-matrices:
  * x_rho [count][k], X_rho [count][k(k+1)/2] (upper triangle, row-major).  Writes ascending
  * eigenvalues [count][k+1] and, if evecs != NULL, eigenvectors [count][k+1][k+1] with

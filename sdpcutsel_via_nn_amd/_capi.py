@@ -49,6 +49,8 @@ SIGNATURES = {
     "sdpcut_gather_scores_device": [_vp, _c.c_int64, _vp, _vp, _vp],
     "sdpcut_cut_rows": [_vp, _c.c_int64, _i64p, _dp, _dp, _dp, _i64p, _i32p],
     "sdpcut_select_round": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _i64p, _dp, _dp, _dp, _dp, _i32p, _i64p, _i64p, _i32p, _i64p],
+    "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
+    "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
@@ -291,6 +293,26 @@ class Scorer(object):
                     n_total=int(n_total.value), new_strat=int(new_strat.value),
                     counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]),
                                   nb_positive=int(cnt[3])))
+
+    # ------------------------------------------------------------------ sharded round (multi-GPU)
+    def shard_head_device(self, strat, count, d_record_ptr):
+        """enqueue this shard's packed head record (8 + 2*count int64 words); no host sync"""
+        self._check(self._lib.sdpcut_shard_head_device(self._h, int(strat), int(count), _vp(d_record_ptr)))
+
+    def shard_finish_round(self, world, count, d_allrec_ptr, sel_size):
+        """merge the gathered records, cut rows of this shard's entries
+        -> dict(headers [world, 8], idx, score, lam, coef, rhs, ks), each of sel_size entries"""
+        m, ld = int(sel_size), self.row_len
+        key = (int(world), m, ld)
+        if getattr(self, "_shard_cap", None) != key:
+            self._shard_bufs = (np.empty((int(world), 8), dtype=np.int64), np.empty(m, dtype=np.int64), np.empty(m),
+                                np.empty(m), np.empty((m, ld)), np.empty(m), np.empty(m, dtype=np.int32))
+            self._shard_cap = key
+        hdr, idx, sc, lam, coef, rhs, ks = self._shard_bufs
+        self._check(self._lib.sdpcut_shard_finish_round(
+            self._h, int(world), int(count), _vp(d_allrec_ptr), m, ld, _ptr(hdr, _i64p), _ptr(idx, _i64p),
+            _ptr(sc, _dp), _ptr(lam, _dp), _ptr(coef, _dp), _ptr(rhs, _dp), _ptr(ks, _i32p)))
+        return dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks)
 
     # ------------------------------------------------------------------ triangle inequalities
     def tri_preprocess(self, adjacency):

@@ -18,6 +18,17 @@ int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg)
     return code;
 }
 
+int ensure_stage(sdpcut_ctx *h, size_t bytes)
+{
+    if (bytes <= h->stage_bytes) return 0;
+    hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->d_stage, bytes));
+    h->stage_bytes = bytes;
+    return 0;
+}
+
 extern "C" {
 
 int sdpcut_version(void) { return 100; }
@@ -387,17 +398,6 @@ int sdpcut_get_scores(sdpcut_handle h, double *eigmin, double *obj_improve)
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SDPCUT_OK;
-}
-
-static int ensure_stage(sdpcut_ctx *h, size_t bytes)
-{
-    if (bytes <= h->stage_bytes) return 0;
-    hipFree(h->d_stage);
-    h->d_stage = nullptr;
-    h->stage_bytes = 0;
-    HIP_TRY(h, hipMalloc(&h->d_stage, bytes));
-    h->stage_bytes = bytes;
-    return 0;
 }
 
 static int check_rank_args(sdpcut_ctx *h, int strat)

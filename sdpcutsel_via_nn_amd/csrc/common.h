@@ -95,6 +95,7 @@ struct sdpcut_ctx {
 };
 
 int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
+int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage
 
 #define HIP_TRY(h, expr)                                                                   \
     do {                                                                                   \

@@ -647,7 +647,8 @@ __device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *var
 // device-side length of a ranking that the host has not read yet).  coef rows have stride
 // coef_ld >= k + k(k+1)/2 of the largest candidate; cols (stride SDPCUT_ROW_LD) is optional.
 __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64_t *d_limit, const int64_t *idx,
-                                                      int64_t idx_base, const int32_t *set5, const int32_t *ks,
+                                                      int64_t idx_base, int64_t n_local, const int32_t *set5,
+                                                      const int32_t *ks,
                                                       const double *vars, int32_t nv, int64_t L, double *lam,
                                                       double *coef, int coef_ld, double *rhs, int64_t *cols,
                                                       int32_t *ks_out)
@@ -656,6 +657,15 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
     if (d_limit && *d_limit < count) count = *d_limit;
     if (i >= count) return;
     const int64_t c = idx[i] - idx_base;
+    if (c < 0 || c >= n_local) {   // a candidate of another shard (sdpcut_shard_finish_round): no row here
+        ks_out[i] = 0;
+        lam[i] = __builtin_nan("");
+        rhs[i] = 0.0;
+        for (int m = 0; m < coef_ld; ++m) coef[i * coef_ld + m] = 0.0;
+        if (cols)
+            for (int m = 0; m < SDPCUT_ROW_LD; ++m) cols[i * SDPCUT_ROW_LD + m] = -1;
+        return;
+    }
     const int k = ks[c];
     const int32_t *s5 = set5 + c * 5;
     double co[SDPCUT_ROW_LD];
@@ -802,7 +812,7 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
     if (count == 0) return 0;
     const int grid = (int)((count + 63) / 64);
     hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_limit, d_idx, idx_base,
-                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
+                       h->N, h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
                        d_ks);
     HIP_TRY(h, hipGetLastError());
     return 0;

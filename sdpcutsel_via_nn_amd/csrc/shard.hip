@@ -1,0 +1,148 @@
+// Sharded selection round (SURVEY.md section 8 e): the two device-side halves around the one
+// RCCL all-gather of a multi-GPU round, each enqueued without host synchronisation.
+//
+//   sdpcut_shard_head_device   local head of the ranking -> one packed int64 record
+//                              [class size, nb_violated, nb_positive, k_eff, 0,0,0,0 | scores | ids]
+//                              (fp64 bit-cast; unused slots = (-inf, INT64_MAX)); the counters are
+//                              written by a kernel from device memory, the host never sees them here
+//   (caller)                   all_gather_into_tensor of the records (torch.distributed / RCCL)
+//   sdpcut_shard_finish_round  unpack -> replicated merge (score desc, id asc) -> eigen-cut rows of
+//                              the merged head that belong to THIS shard -> one D2H, one sync
+#include <cstring>
+
+#include "common.h"
+#include "keys.h"
+
+#define SHARD_HDR 8
+
+__global__ void shard_fill_kernel(int64_t count, int64_t *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < SHARD_HDR) rec[i] = 0;
+    if (i < count) {
+        rec[SHARD_HDR + i] = __double_as_longlong(-__builtin_huge_val());
+        rec[SHARD_HDR + count + i] = 0x7fffffffffffffffLL;
+    }
+}
+
+__global__ void shard_header_kernel(int64_t *rec, const int64_t *c4, int64_t n, int is_opt)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        rec[0] = is_opt ? n : c4[0];      // length of this shard's list (class size)
+        rec[1] = c4[1];                   // nb_violated
+        rec[2] = c4[2];                   // nb_positive
+        rec[3] = c4[3];                   // entries actually written
+    }
+}
+
+// Replicated merge of the gathered heads.  Every head is already ordered (score descending, id
+// ascending) -- the order a stable sort gives on one list (cut_select_qp.py:601, :625, :653) -- so
+// the position of an entry in the merged list is its own position plus, per other rank, the number
+// of entries that precede it there (one binary search each).  Pads (-inf, INT64_MAX) compare equal
+// across ranks and are ordered by rank, which keeps the positions a permutation.
+__global__ void shard_mergerank_kernel(int world, int64_t count, const int64_t *allrec, int64_t sel, double *scores,
+                                       int64_t *ids, int64_t *headers)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rl = SHARD_HDR + 2 * count;
+    if (i < (int64_t)world * SHARD_HDR) headers[i] = allrec[(i / SHARD_HDR) * rl + (i % SHARD_HDR)];
+    if (i >= (int64_t)world * count) return;
+    const int r = (int)(i / count);
+    const int64_t e = i - (int64_t)r * count;
+    const int64_t sbits = allrec[r * rl + SHARD_HDR + e];
+    const int64_t id = allrec[r * rl + SHARD_HDR + count + e];
+    const uint64_t key = key_of(__longlong_as_double(sbits));
+    int64_t pos = e;
+    for (int q = 0; q < world; ++q) {
+        if (q == r) continue;
+        const int64_t *qs = allrec + q * rl + SHARD_HDR, *qi = qs + count;
+        int64_t lo = 0, hi = count;   // first entry of rank q that does NOT precede (key, id, r)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const uint64_t km = key_of(__longlong_as_double(qs[mid]));
+            const int64_t im = qi[mid];
+            const bool before = km > key || (km == key && (im < id || (im == id && q < r)));
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        pos += lo;
+    }
+    if (pos < sel) {
+        scores[pos] = __longlong_as_double(sbits);
+        ids[pos] = id;
+    }
+}
+
+extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t count, void *d_record)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (count < 1 || count > 8192 || !d_record) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: count must be 1..8192");
+    if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_PART_STRONG)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: strategy must be 1, 2 or SDPCUT_PART_STRONG");
+    const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
+                          : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
+    if ((h->scored & need) != need) return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int64_t *rec = (int64_t *)d_record;
+    hipLaunchKernelGGL(shard_fill_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, h->stream, count, rec);
+    if (h->N > 0) {
+        const int64_t *d_c4 = nullptr;
+        int rc = rank_fast_enqueue(h, strat, 0, count, rec + SHARD_HDR + count, (double *)(rec + SHARD_HDR), &d_c4);
+        if (rc < 0) return rc;
+        if (rc != 1) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: request not eligible for the select path");
+        hipLaunchKernelGGL(shard_header_kernel, dim3(1), dim3(64), 0, h->stream, rec, d_c4, h->N,
+                           strat == SDPCUT_STRAT_OPT ? 1 : 0);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SDPCUT_OK;
+}
+
+extern "C" int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count, const void *d_allrec,
+                                         int64_t sel_size, int32_t coef_ld, int64_t *headers_out, int64_t *idx_out,
+                                         double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || !headers_out ||
+        !idx_out || !score_out || !lam_min || !coef || !rhs || !ks)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish_round arguments");
+    if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD) return sdpcut_fail(h, SDPCUT_EINVAL, "bad coef_ld");
+    if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t tot = (size_t)world * count, s = (size_t)sel_size;
+    // device block, returned by ONE transfer: headers | ids | scores | lam | rhs | coef | ks
+    const size_t hdr_b = (size_t)world * SHARD_HDR * 8;
+    const size_t ret_bytes = hdr_b + s * 8 * (4 + (size_t)coef_ld) + s * 4;
+    int rc = ensure_stage(h, ret_bytes + 64);
+    if (rc) return rc;
+    if (h->pinned_bytes < ret_bytes) {
+        if (h->pinned) (void)hipHostFree(h->pinned);
+        h->pinned = nullptr;
+        h->pinned_bytes = 0;
+        HIP_TRY(h, hipHostMalloc(&h->pinned, ret_bytes, hipHostMallocDefault));
+        h->pinned_bytes = ret_bytes;
+    }
+    char *p = (char *)h->d_stage;
+    int64_t *d_hdr = (int64_t *)p; p += hdr_b;
+    int64_t *d_mi = (int64_t *)p; p += s * 8;
+    double *d_ms = (double *)p; p += s * 8;
+    double *d_lam = (double *)p; p += s * 8;
+    double *d_rhs = (double *)p; p += s * 8;
+    double *d_coef = (double *)p; p += s * 8 * (size_t)coef_ld;
+    int32_t *d_ks = (int32_t *)p;
+    const size_t nthr = tot > (size_t)world * SHARD_HDR ? tot : (size_t)world * SHARD_HDR;
+    hipLaunchKernelGGL(shard_mergerank_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, h->stream, (int)world,
+                       count, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, d_hdr);
+    // rows of the merged head that live on this shard (the others are marked ks = 0, lam = NaN)
+    rc = launch_cut_rows(h, sel_size, nullptr, d_mi, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const char *q = (const char *)h->pinned;
+    std::memcpy(headers_out, q, hdr_b); q += hdr_b;
+    std::memcpy(idx_out, q, s * 8); q += s * 8;
+    std::memcpy(score_out, q, s * 8); q += s * 8;
+    std::memcpy(lam_min, q, s * 8); q += s * 8;
+    std::memcpy(rhs, q, s * 8); q += s * 8;
+    std::memcpy(coef, q, s * 8 * (size_t)coef_ld); q += s * 8 * (size_t)coef_ld;
+    std::memcpy(ks, q, s * 4);
+    return SDPCUT_OK;
+}

@@ -50,6 +50,26 @@ class DeviceOps(object):
                 sec[:w] = tmp_o
         return scores, ids, sec, total, counters
 
+    # -- fused round (sdpcut_shard_head_device / sdpcut_shard_finish_round) ----------------
+    max_head = 8192
+
+    def shard_head(self, strat, count):
+        """packed head record of this shard, enqueued on the current stream (no host sync)"""
+        rec = torch.empty(8 + 2 * count, dtype=torch.int64, device=self.device)
+        self.scorer.shard_head_device(strat, count, rec.data_ptr())
+        return rec
+
+    def shard_finish(self, world, count, allrec, sel_size):
+        return self.scorer.shard_finish_round(world, count, allrec.data_ptr(), sel_size)
+
+    def rows_of(self, global_ids):
+        """eigen-cut rows of the entries of ``global_ids`` (numpy) that live on this shard
+        -> (mine mask, lam, coef [., row_len], rhs, ks)"""
+        sc = self.scorer
+        mine = (global_ids >= sc.base) & (global_ids < sc.base + sc.N)
+        lam, coef, rhs, _, ks = sc.cut_rows(global_ids[mine] - sc.base)
+        return mine, lam, coef[:, :sc.row_len], rhs, ks
+
     def merge(self, scores, ids, count_out, secondary=None):
         out_s = torch.empty(count_out, dtype=torch.float64, device=self.device)
         out_i = torch.empty(count_out, dtype=torch.int64, device=self.device)
@@ -154,3 +174,40 @@ class ShardedSelector(object):
         new_strat = 1 if strong / sel_size < violated / self.n_global else 4     # cut_select_qp.py:630
         return dict(ids=ids, scores=scores, new_strat=new_strat, n_total=self.n_global,
                     counters=dict(strong=strong, violated=violated))
+
+    def select_round(self, strat, sel_size):
+        """Selection AND eigen-cut rows of one round (cut_select_qp.py:165-182) over all shards
+        -> dict(ids, scores, mine, lam, coef, rhs, ks, new_strat, n_total, counters), numpy.
+
+        ``ids`` / ``scores`` are the replicated global head; ``mine`` marks the entries whose
+        candidate lives on this rank, and lam/coef/rhs/ks hold the rows of exactly those (in head
+        order) -- every rank generates the rows of its own candidates, nothing else moves.
+
+        Common regime (strategies 1 and 2; strategy 4 with at least sel_size strong candidates
+        overall): ONE collective and ONE host synchronisation per round -- the shard's head and
+        its counters are packed on the device, all-gathered, merged and turned into rows by
+        two library calls (shard_head / shard_finish).  Otherwise :meth:`select` runs."""
+        if strat not in (1, 2, 4):
+            raise ValueError("strategy must be 1, 2 or 4")
+        sel = min(int(sel_size), self.n_global)
+        ops = self.ops
+        if 1 <= sel <= getattr(ops, "max_head", 0):
+            rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel)
+            out = ops.shard_finish(self.world, sel, self._all_gather(rec), sel)
+            g = out["headers"].sum(axis=0)
+            length = int(g[0])
+            if strat != 4 or length >= sel:
+                valid = min(sel, length)
+                mine = out["ks"][:valid] > 0
+                cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))
+                if strat == 4:
+                    cnt.update(strong=sel, violated=sel)
+                return dict(ids=out["idx"][:valid], scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
+                            mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
+                            rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine], new_strat=strat,
+                            n_total=self.n_global if strat != 1 else length, counters=cnt)
+        res = self.select(strat, sel_size)
+        ids = res["ids"].cpu().numpy()
+        mine, lam, coef, rhs, ks = ops.rows_of(ids)
+        return dict(ids=ids, scores=res["scores"].cpu().numpy(), mine=mine, lam=lam, coef=coef, rhs=rhs, ks=ks,
+                    new_strat=res["new_strat"], n_total=res["n_total"], counters=res["counters"])

@@ -56,10 +56,84 @@ for vv in points:
             assert r["new_strat"] == new_strat
             if strat == 4:
                 assert r["counters"]["strong"] == cnt["strong"] and r["counters"]["violated"] == cnt["violated"]
+            # fused round (shard_head / all-gather / shard_finish): same head + rows of the own entries
+            q = sel.select_round(strat, sel_size)
+            assert np.array_equal(q["ids"], order[:k]), (strat, sel_size, rank)
+            assert np.array_equal(q["scores"], score[:k] + 0.0), (strat, sel_size)
+            assert q["new_strat"] == new_strat
+            if strat == 4:
+                assert q["counters"]["strong"] == cnt["strong"] and q["counters"]["violated"] == cnt["violated"]
+            own = (order[:k] >= lo) & (order[:k] < lo + n_each)
+            assert np.array_equal(q["mine"], own), (strat, sel_size)
+            lam, coef, rhs, _, ks = sc.cut_rows(order[:k][own] - lo)
+            assert np.array_equal(q["lam"], lam) and np.array_equal(q["rhs"], rhs) and np.array_equal(q["ks"], ks)
+            assert np.array_equal(q["coef"], coef[:, :9])
+            assert np.allclose(q["lam"], E[order[:k][own]], rtol=1e-9, atol=1e-12)
 sc.close()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
+
+
+def test_shard_round_ragged_shards_one_process(oracle):
+    """sdpcut_shard_head_device / sdpcut_shard_finish_round with four handles standing in for four
+    ranks (shards of 20000, 0, 7 and 12000 candidates; the records are concatenated instead of
+    all-gathered): merged head = the single-list ranking head, rows = each shard's own rows."""
+    import numpy as np
+    import torch
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    from sdpcutsel_via_nn_amd.distributed import DeviceOps
+
+    dev = torch.device("cuda", 0)
+    sizes = [20000, 0, 7, 12000]
+    bases = np.concatenate([[0], np.cumsum(sizes)])
+    nv = 40
+    wl = synthetic.make_workload(nb_vars=nv, k=3, count=int(bases[-1]), seed=23)
+    opss = []
+    for r, n in enumerate(sizes):
+        sc = _capi.Scorer(0)
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(nv, wl["Q_arr"])
+        lo = int(bases[r])
+        sc.set_candidates(wl["set_inds"][lo:lo + n], wl["ks"][lo:lo + n], global_base=lo)
+        opss.append(DeviceOps(sc, dev))
+    try:
+        E, O = [], []
+        for ops in opss:
+            ops.scorer.set_point(wl["vars_values"])
+            ops.scorer.score(_capi.EIG | _capi.NN)
+            e, o = ops.scorer.get_scores()
+            E.append(e[:ops.scorer.N]); O.append(o[:ops.scorer.N])
+        E, O = np.concatenate(E), np.concatenate(O)
+        n_strong = int(((O > 0) & (E < -1e-15)).sum())
+        assert n_strong > 50
+        for strat, code in ((1, 1), (2, 2), (4, _capi.PART_STRONG)):
+            for sel in (1, 29, 50, 5000, 8192):
+                if strat == 4 and sel > n_strong:
+                    continue                       # the general regime is ShardedSelector.select's business
+                allrec = torch.cat([ops.shard_head(code, sel) for ops in opss])
+                order, score, _, _ = oracle.rank_arrays(strat, O, E, sel)
+                k = min(sel, order.shape[0])
+                for r, ops in enumerate(opss):
+                    out = ops.shard_finish(len(sizes), sel, allrec, sel)
+                    g = out["headers"].sum(axis=0)
+                    assert int(g[0]) == (order.shape[0] if strat != 4 else n_strong)
+                    assert int(g[1]) == int((E < -1e-15).sum()) and int(g[2]) == int((O > 0).sum())
+                    assert np.array_equal(out["idx"][:k], order[:k]), (strat, sel, r)
+                    assert np.array_equal(out["score"][:k] + (1000.0 if strat == 4 else 0.0), score[:k] + 0.0)
+                    assert np.all(out["idx"][k:] == np.iinfo(np.int64).max) and np.all(out["ks"][k:] == 0)
+                    lo, n = int(bases[r]), sizes[r]
+                    own = (order[:k] >= lo) & (order[:k] < lo + n)
+                    assert np.array_equal(out["ks"][:k] > 0, own)
+                    assert np.all(np.isnan(out["lam"][:k][~own]))
+                    if own.any():
+                        lam, coef, rhs, _, ks = ops.scorer.cut_rows(order[:k][own] - lo)
+                        assert np.array_equal(out["lam"][:k][own], lam) and np.array_equal(out["rhs"][:k][own], rhs)
+                        assert np.array_equal(out["coef"][:k][own], coef[:, :out["coef"].shape[1]])
+                        assert np.array_equal(out["ks"][:k][own], ks)
+    finally:
+        for ops in opss:
+            ops.scorer.close()
 
 
 def test_two_ranks_one_gpu_sharded_selection(oracle, tmp_path):

@@ -162,6 +162,28 @@ class FakeOps(object):
         keys = (ids.numpy(), -secondary.numpy(), -scores.numpy()) if secondary is not None else (ids.numpy(), -scores.numpy())
         o = np.lexsort(keys)[:count_out]
         return scores[o], ids[o]
+    # fused round: packed record / merge + rows of the own entries (row = the candidate's lam only)
+    max_head = 8192
+    def shard_head(self, strat, count):
+        s, i, _, total, _ = self.local_head(strat, count, count)
+        n = self.obj.shape[0]
+        hdr = [n if strat == 2 else total, int((self.lam < oracle.THRES_NEG_EIGVAL).sum()), int((self.obj > 0).sum()),
+               min(count, total), 0, 0, 0, 0]
+        return torch.cat([torch.tensor(hdr, dtype=torch.int64), s.view(torch.int64), i])
+    def rows_of(self, ids):
+        n = self.obj.shape[0]
+        mine = (ids >= self.base) & (ids < self.base + n)
+        c = int(mine.sum())
+        return mine, self.lam[ids[mine] - self.base], np.zeros((c, 9)), np.zeros(c), np.full(c, 3, dtype=np.int32)
+    def shard_finish(self, world, count, allrec, sel):
+        a = allrec.view(world, -1).numpy()
+        s = np.ascontiguousarray(a[:, 8:8 + count]).reshape(-1).view(np.float64)
+        i = np.ascontiguousarray(a[:, 8 + count:]).reshape(-1)
+        o = np.lexsort((i, -s))[:sel]
+        mine, lam_m, _, _, _ = self.rows_of(i[o])
+        lam = np.full(sel, np.nan); lam[mine] = lam_m
+        return dict(headers=a[:, :8].copy(), idx=i[o], score=s[o], lam=lam, coef=np.zeros((sel, 9)), rhs=np.zeros(sel),
+                    ks=np.where(mine, 3, 0).astype(np.int32))
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -185,6 +207,16 @@ def main():
             assert r["new_strat"] == new_strat, (case, strat)
             if strat == 4:
                 assert r["counters"]["strong"] == cnt["strong"] and r["counters"]["violated"] == cnt["violated"]
+            # the fused round: same head, plus the rows of this rank's own entries
+            q = sel_obj.select_round(strat, sel)
+            assert np.array_equal(q["ids"], order[:k]), (case, strat, rank)
+            assert np.array_equal(q["scores"], score[:k]), (case, strat)
+            assert q["new_strat"] == new_strat, (case, strat)
+            own = (order[:k] >= lo) & (order[:k] < lo + n_each)
+            assert np.array_equal(q["mine"], own), (case, strat)
+            assert np.array_equal(q["lam"], lam[order[:k][own]]) and q["ks"].shape[0] == int(own.sum())
+            if strat == 4:
+                assert q["counters"]["strong"] == cnt["strong"] and q["counters"]["violated"] == cnt["violated"]
     dist.destroy_process_group()
     print("rank", rank, "ok")
 
