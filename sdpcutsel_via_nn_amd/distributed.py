@@ -7,9 +7,10 @@ exactly one exchange step per ranking: an all-gather of the per-shard head
 replicated merge keyed (score descending, id ascending) -- the same order the reference's
 stable sort gives on one list (cut_select_qp.py:601, :625, :653).  Counters are all-reduced.
 
-The combined strategy's early-exit scan (cut_select_qp.py:606-623) is merged class by class
-(STRONG / LOW / REST partial rankings of the C-ABI), which reproduces the head of the
-single-list result; see :meth:`ShardedSelector.select`.
+The combined strategy's early-exit scan (cut_select_qp.py:606-623) is resolved through the
+merged head of the STRONG class (positive and violated), see :meth:`ShardedSelector.select`.
+:meth:`ShardedSelector.select_round` is the whole round (selection + eigen-cut rows of the own
+candidates) with one collective and one host synchronisation (csrc/shard.hip).
 
 With the "gloo" backend (CPU rehearsal of the choreography, used by the tests) the gathered
 buffers are staged through host memory; the ranking and the merge still run on the device.
