@@ -144,6 +144,64 @@ __device__ __forceinline__ double tansig(double n)
     return fma(2.0, q, -1.0);
 }
 
+// exp(-2n) + 1, the denominator of tansig, for tansig4.  y = -2n is clamped to 176 here so that
+// the product of four denominators stays finite (tansig(-88) is -1 to 2e-76 either way).
+__device__ __forceinline__ double tansig_den(double n)
+{
+    const double y8 = fmin(n * -0.25, 22.0);
+    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
+    double r = fma(k, -8.66433975461404770613e-02, y8);              // ln2_hi / 8
+    r = fma(k, -2.38526866158823462503e-11, r);                      // ln2_lo / 8
+    double p = 2.48015873015873015873e-05;              // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);          // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);          // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);          // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);          // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);          // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    return ldexp(p, (int)k) + 1.0;
+}
+
+// Four tansig values with ONE reciprocal: 1/d_i = (1 / (d0 d1 d2 d3)) * prod_{j != i} d_j.
+// v_rcp_f64 plus its refinement is 6 issue slots; sharing it costs 12 slots per four values
+// instead of 24 (the kernel is bound by the VALU/MFMA instruction count).  Every d_i >= 1 and
+// <= 1 + e^176, so the product neither underflows nor overflows; the extra roundings stay
+// below 5e-16 relative.
+__device__ __forceinline__ void tansig4(double &v0, double &v1, double &v2, double &v3)
+{
+    const double d0 = tansig_den(v0), d1 = tansig_den(v1), d2 = tansig_den(v2), d3 = tansig_den(v3);
+    const double d01 = d0 * d1, d23 = d2 * d3;
+    const double dd = d01 * d23;
+    double q = __builtin_amdgcn_rcp(dd);
+    const double e = fma(-dd, q, 1.0);
+    q = fma(q, fma(e, e, e), q);
+    q = q + q;
+    const double q01 = q * d23, q23 = q * d01;          // 2/(d0 d1), 2/(d2 d3)
+    v0 = fma(q01, d1, -1.0);
+    v1 = fma(q01, d0, -1.0);
+    v2 = fma(q23, d3, -1.0);
+    v3 = fma(q23, d2, -1.0);
+}
+
+// tansig of one MFMA C/D fragment (rows 16 t + 4 r + q, r = 0..3); rows >= H are padding -> 0
+template <int H>
+__device__ __forceinline__ d4 tansig_tile(d4 c, int t)
+{
+    double v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+    tansig4(v0, v1, v2, v3);
+    d4 out;
+    out[0] = (16 * t + 0 < H) ? v0 : 0.0;
+    out[1] = (16 * t + 4 < H) ? v1 : 0.0;
+    out[2] = (16 * t + 8 < H) ? v2 : 0.0;
+    out[3] = (16 * t + 12 < H) ? v3 : 0.0;
+    return out;
+}
+
 // The LDS strips of the MFMA kernel (feat, ynn) are private to one wave.  A wave's LDS
 // instructions are issued and serviced in program order, so a write followed by a read of
 // another lane's slot needs no workgroup barrier -- only that the compiler keeps the order and
@@ -160,20 +218,30 @@ __device__ __forceinline__ void wave_lds_sync()
 // neuron u over the k-slots it owns (n = 4 s + q); the four k-slot lanes of a candidate column
 // (lane, lane^16, lane^32, lane^48) are summed, and lane q keeps neuron u = q in register 0 of
 // the last row tile -- exactly where the MFMA C/D layout would have put it.
+// Both column tiles of a pass share ONE tansig evaluation: after the two xor-adds every lane of a
+// column holds the full sums, so lanes q = 0, 1 take tile j = 0 and lanes q = 2, 3 tile j = 1
+// (neuron u = q & 1); a final xor-32 shuffle hands the j = 1 values to lanes q = 0, 1.
 template <int NT>
-__device__ __forceinline__ d4 tail_rows(const double (&ts)[NT ? NT : 1], const double *bias, int q)
+__device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], const double *bias, int q, d4 &out0,
+                                           d4 &out1)
 {
+    static_assert(NT <= 2, "at most two tail neurons");
     double pre = 0.0;
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        double v = ts[u];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        pre = (q == u) ? v + bias[u] : pre;
-    }
-    d4 out = {0.0, 0.0, 0.0, 0.0};
-    out[0] = (q < NT) ? tansig(pre) : 0.0;
-    return out;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            double v = ts[j][u];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            pre = (q == 2 * j + u) ? v + bias[u] : pre;
+        }
+    const double t = tansig(pre);
+    const double t1 = __shfl_xor(t, 32);
+    out0 = d4{0.0, 0.0, 0.0, 0.0};
+    out1 = d4{0.0, 0.0, 0.0, 0.0};
+    out0[0] = (q < NT) ? t : 0.0;
+    out1[0] = (q < NT) ? t1 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -257,10 +325,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bin[s][j], cur[t][j], 0, 0, 0);
                 }
 #pragma unroll
-                for (int j = 0; j < J; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
+                for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H>(cur[t][j], t);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (NT > 0) {
@@ -277,8 +342,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                         for (int j = 0; j < J; ++j) ts[j][u] = fma(bin[s][j], w, ts[j][u]);
                     }
-#pragma unroll
-                for (int j = 0; j < J; ++j) cur[T - 1][j] = tail_rows<NT>(ts[j], net.bias + 16 * (T - 1), q);
+                tail_rows2<NT>(ts, net.bias + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
             }
             wf += T * S0 * 64;
             // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
@@ -315,10 +379,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int j = 0; j < J; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            cur[t][j][r] = (16 * t + 4 * r < H) ? tansig(cur[t][j][r]) : 0.0;
+                    for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H>(cur[t][j], t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (NT > 0) {
@@ -335,8 +396,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                             for (int j = 0; j < J; ++j) ts[j][u] = fma(prev[s / 4][j][s % 4], w, ts[j][u]);
                         }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) cur[T - 1][j] = tail_rows<NT>(ts[j], net.bias + l * 64 + 16 * (T - 1), q);
+                    tail_rows2<NT>(ts, net.bias + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
                 }
                 wf += T * SH * 64;
             }
