@@ -193,7 +193,9 @@ template <int H>
 __device__ __forceinline__ d4 tansig_tile(d4 c, int t)
 {
     double v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+#ifndef SDPCUT_ABL_NOTANSIG     // tools/build_ablation.sh: timing experiments only
     tansig4(v0, v1, v2, v3);
+#endif
     d4 out;
     out[0] = (16 * t + 0 < H) ? v0 : 0.0;
     out[1] = (16 * t + 4 < H) ? v1 : 0.0;
@@ -243,6 +245,19 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
     out0[0] = (q < NT) ? t : 0.0;
     out1[0] = (q < NT) ? t1 : 0.0;
 }
+
+// Timing experiments (tools/build_ablation.sh; results are wrong by design): drop the bias or
+// weight-fragment loads to see what their latency costs.
+#ifdef SDPCUT_ABL_NOBIAS
+#define BIAS_AT(i) (0.125 + 0.0 * (double)(i))
+#else
+#define BIAS_AT(i) net.bias[i]
+#endif
+#ifdef SDPCUT_ABL_NOWLOAD
+#define WFRAG_AT(i) (0.01 * (double)((i) & 7))
+#else
+#define WFRAG_AT(i) wf[i]
+#endif
 
 // ------------------------------------------------------------------------------------------
 // MFMA kernel.  K candidate size, H hidden width, NH hidden layers.
@@ -314,12 +329,12 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             for (int t = 0; t < TM; ++t) {
                 d4 bias;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bias[r] = net.bias[16 * t + 4 * r + q];
+                for (int r = 0; r < 4; ++r) bias[r] = BIAS_AT(16 * t + 4 * r + q);
 #pragma unroll
                 for (int j = 0; j < J; ++j) cur[t][j] = bias;
 #pragma unroll
                 for (int s = 0; s < S0; ++s) {
-                    const double a = wf[(t * S0 + s) * 64 + lane];
+                    const double a = WFRAG_AT((t * S0 + s) * 64 + lane);
 #pragma unroll
                     for (int j = 0; j < J; ++j)
                         cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bin[s][j], cur[t][j], 0, 0, 0);
@@ -359,18 +374,18 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 constexpr int RD = 4, NG = TM * SH;
                 double ring[RD];
 #pragma unroll
-                for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = wf[g * 64 + lane];
+                for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = WFRAG_AT(g * 64 + lane);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     d4 bias;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bias[r] = net.bias[l * 64 + 16 * t + 4 * r + q];
+                    for (int r = 0; r < 4; ++r) bias[r] = BIAS_AT(l * 64 + 16 * t + 4 * r + q);
 #pragma unroll
                     for (int j = 0; j < J; ++j) cur[t][j] = bias;
 #pragma unroll
                     for (int s = 0; s < SH; ++s) {
                         const int g = t * SH + s;
-                        if (g + RD - 1 < NG) ring[(g + RD - 1) % RD] = wf[(g + RD - 1) * 64 + lane];
+                        if (g + RD - 1 < NG) ring[(g + RD - 1) % RD] = WFRAG_AT((g + RD - 1) * 64 + lane);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < J; ++j)

@@ -8,6 +8,11 @@
 // the lowest-index keys equal to it, exactly what a stable descending sort would keep -- and
 // orders them by (key desc, index asc) with a counting sort spread over the chip.
 //
+// The passes stop as soon as the keys above the threshold bin plus the whole bin fit the sort
+// buffers (<= 8192): that superset is compacted and sorted, and only its first k entries are
+// emitted.  Spread-out scores need 2-3 of the 8 digits (the remaining launches return at once);
+// masses of equal keys run to the last digit, where ties are cut by index.
+//
 // No host round trip anywhere: the last workgroup to finish a histogram pass (ticket counter)
 // resolves that digit and publishes (prefix, need) for the next launch; the kernel boundary is
 // the release/acquire.  Histogram cells and counters are written with device-scope atomics
@@ -25,6 +30,7 @@ enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3 };
 struct TkState {
     uint64_t prefix;   // digits resolved so far, in place
     int64_t need;      // how many of the keys matching the prefix are still wanted (0: nothing)
+    int64_t stop;      // 1: the selection was closed early (see resolve_digit), later passes are no-ops
 };
 
 struct TopkWs {
@@ -34,6 +40,7 @@ struct TopkWs {
     uint32_t done[8];        // ticket counters of the passes
     uint32_t blk_eq[TK_MAXBLK];
     uint32_t blk_gt[TK_MAXBLK];
+    int64_t n_sel;           // entries compacted by tk_write_kernel (>= k_eff after an early stop)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -85,8 +92,25 @@ __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
     const int64_t here = suf[t], above = (t < 255) ? suf[t + 1] : 0;
     if (need >= 1) {
         if (here >= need && above < need) {       // exactly one bin
-            ws->state[p + 1].prefix = prefix | ((uint64_t)t << (8 * (7 - p)));
-            ws->state[p + 1].need = need - above;
+            const uint64_t pre = prefix | ((uint64_t)t << (8 * (7 - p)));
+            // Early stop: the keys above this bin (k_eff - (need - above) of them) plus the WHOLE bin
+            // fit the sort buffers, so take that superset -- every key >= the bin's lowest value --
+            // and let the final sort put the wanted k_eff first.  With 10^6 spread-out scores this
+            // happens after 2-3 digits; masses of equal keys keep the passes going to the last digit,
+            // where ties are cut by index as before.
+            const int64_t k_eff = ld_i64(&ws->counters[3]);
+            const int64_t in_bin = here - above;
+            const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
+            if (p < 7 && superset <= TK_MAXK) {
+                for (int qq = p + 1; qq <= 8; ++qq) {
+                    ws->state[qq].prefix = pre;
+                    ws->state[qq].need = in_bin;       // every key equal to the bin's lowest value, if any
+                    ws->state[qq].stop = 1;
+                }
+            } else {
+                ws->state[p + 1].prefix = pre;
+                ws->state[p + 1].need = need - above;
+            }
         }
     } else if (t == 0) {
         ws->state[p + 1].prefix = 0;
@@ -170,6 +194,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
     hist[threadIdx.x] = 0;
     __syncthreads();
     const TkState st = ws->state[p];
+    if (st.stop) return;                              // uniform: selection already closed
     if (st.need >= 1) {                               // uniform
         const int shift = 8 * (7 - p);
         const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
@@ -213,25 +238,35 @@ __global__ __launch_bounds__(TK_THREADS) void tk_count_kernel(int64_t n, int64_t
 __global__ __launch_bounds__(TK_THREADS) void tk_write_kernel(int64_t n, int64_t chunk, const uint64_t *keys, TopkWs *ws,
                                                               uint64_t *sel_key, uint32_t *sel_idx)
 {
-    __shared__ uint32_t red_gt[TK_THREADS], red_eq[TK_THREADS];
+    __shared__ uint32_t red_gt[TK_THREADS], red_eq[TK_THREADS], all_gt[TK_THREADS], all_eq[TK_THREADS];
     __shared__ uint32_t wave_cnt[TK_THREADS / 64];
     __shared__ uint32_t gt_local;
     const TkState st = ws->state[8];
     if (st.need < 1) return;
     const uint64_t T = st.prefix;
-    const int64_t greater = ws->counters[3] - st.need;
-    uint32_t pg = 0, pe = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += TK_THREADS) { pg += ws->blk_gt[b]; pe += ws->blk_eq[b]; }
+    uint32_t pg = 0, pe = 0, tg = 0, te = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += TK_THREADS) {
+        const uint32_t g = ws->blk_gt[b], e = ws->blk_eq[b];
+        tg += g; te += e;
+        if (b < (int)blockIdx.x) { pg += g; pe += e; }
+    }
     red_gt[threadIdx.x] = pg;
     red_eq[threadIdx.x] = pe;
+    all_gt[threadIdx.x] = tg;
+    all_eq[threadIdx.x] = te;
     if (threadIdx.x == 0) gt_local = 0;
     __syncthreads();
     for (int off = TK_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { red_gt[threadIdx.x] += red_gt[threadIdx.x + off]; red_eq[threadIdx.x] += red_eq[threadIdx.x + off]; }
+        if (threadIdx.x < off) {
+            red_gt[threadIdx.x] += red_gt[threadIdx.x + off]; red_eq[threadIdx.x] += red_eq[threadIdx.x + off];
+            all_gt[threadIdx.x] += all_gt[threadIdx.x + off]; all_eq[threadIdx.x] += all_eq[threadIdx.x + off];
+        }
         __syncthreads();
     }
     const int64_t base_gt = red_gt[0];
     int64_t base_eq = red_eq[0];
+    const int64_t greater = all_gt[0];                 // keys above the threshold, over all blocks
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws->n_sel = greater + (st.need < (int64_t)all_eq[0] ? st.need : (int64_t)all_eq[0]);
     const bool want_gt = ws->blk_gt[blockIdx.x] != 0;
     const bool want_eq = ws->blk_eq[blockIdx.x] != 0 && base_eq < st.need;
     if (!want_gt && !want_eq) return;     // uniform
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
 {
     __shared__ uint64_t sk[TK_TILE];
     __shared__ uint32_t si[TK_TILE];
-    const int k_eff = (int)ws->counters[3];
+    const int k_eff = (int)ws->n_sel;              // compacted entries (a superset of the head after an early stop)
     const int lo = blockIdx.x * TK_TILE;
     if (lo >= k_eff) return;                       // uniform
     for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
@@ -322,9 +357,9 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
 {
     __shared__ uint64_t sk[TK_MAXK];
     __shared__ uint32_t si[TK_MAXK];
-    const int k_eff = (int)ws->counters[3];
-    if (blockIdx.x * TK_THREADS >= k_eff) return;   // uniform
-    const int ntiles = (k_eff + TK_TILE - 1) / TK_TILE;
+    const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
+    if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
+    const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
     for (int j = threadIdx.x; j < ntiles * TK_TILE; j += TK_THREADS) {
         sk[j] = tile_key[j];
         si[j] = tile_idx[j];
@@ -349,6 +384,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
         }
         rank += lo;
     }
+    if (rank >= k_eff) return;                                // superset entries beyond the head
     idx_out[rank] = base + (int64_t)ie;
     score_out[rank] = score_of(~ke) + score_add;
 }
@@ -396,7 +432,7 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
     hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
                        h->d_sel_key, h->d_sel_idx);
-    const int ntiles = (int)((k + TK_TILE - 1) / TK_TILE);
+    const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;
     uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
     hipLaunchKernelGGL(tk_tilesort_kernel, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key, h->d_sel_idx,

@@ -14,6 +14,8 @@ def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 6
     nv = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    if os.environ.get("SDPCUT_LIB"):          # a variant built by tools/build_ablation.sh
+        _capi.load_library(os.environ["SDPCUT_LIB"])
     wl = synthetic.make_workload(nb_vars=nv, k=k, count=count, seed=7)
     sc = _capi.Scorer(0)
     sc.set_option(_capi.OPT_TIMING, 1)
@@ -24,9 +26,12 @@ def main():
     variants = (("mfma", _capi.KERNEL_MFMA), ("valu", _capi.KERNEL_VALU), ("simple", _capi.KERNEL_SIMPLE))
     if len(sys.argv) > 4:
         variants = [v for v in variants if v[0] in sys.argv[4].split(",")]
+    flagsets = (("eig", _capi.EIG), ("nn", _capi.NN), ("eig+nn", _capi.EIG | _capi.NN))
+    if len(sys.argv) > 5:
+        flagsets = [f for f in flagsets if f[0] in sys.argv[5].split(",")]
     for name, kv in variants:
         sc.set_option(_capi.OPT_KERNEL, kv)
-        for fname, flags in (("eig", _capi.EIG), ("nn", _capi.NN), ("eig+nn", _capi.EIG | _capi.NN)):
+        for fname, flags in flagsets:
             ts = []
             for it in range(8):
                 sc.score(flags)

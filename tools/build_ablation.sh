@@ -1,0 +1,22 @@
+#!/bin/bash
+# Development aid: build variants of the library with -DSDPCUT_ABL_<X> switches of score.hip
+# (results are WRONG by design; only the kernel time is of interest) into sdpcutsel_via_nn_amd/_abl/.
+# usage: tools/build_ablation.sh NAME1[:FLAG,FLAG] NAME2 ...   e.g.  base nobias:NOBIAS notansig:NOTANSIG
+set -e
+cd "$(dirname "$0")/.."
+P=sdpcutsel_via_nn_amd
+mkdir -p $P/_abl
+python -m $P.build >/dev/null 2>&1
+for spec in "$@"; do
+  name=${spec%%:*}
+  flags=""
+  if [[ "$spec" == *:* ]]; then for f in $(echo ${spec#*:} | tr , ' '); do flags="$flags -DSDPCUT_ABL_$f"; done; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $P/csrc/score.hip -o $P/_abl/score_$name.o &
+done
+wait
+for spec in "$@"; do
+  name=${spec%%:*}
+  objs=$(ls $P/csrc/*.o | grep -v score.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/_abl/lib_$name.so $P/_abl/score_$name.o $objs
+  echo built $P/_abl/lib_$name.so
+done
