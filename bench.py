@@ -114,7 +114,8 @@ def main():
         sc.set_point_device(d_vars.data_ptr())
         if world == 1:
             # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> one D2H
-            res = rows = sc.select_round(4, SEL)
+            # (results land in the handle's pinned host block; copy=False hands out views of it)
+            res = rows = sc.select_round(4, SEL, copy=False)
         else:
             # score the shard -> packed head record -> ONE all-gather (RCCL) -> replicated merge ->
             # each rank generates the rows of its own candidates -> one D2H, one host sync

@@ -184,6 +184,17 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
                         int64_t *idx_out, double *score_out, double *lam_min, double *coef,
                         double *rhs, int32_t *ks, int64_t *n_out, int64_t *n_total,
                         int32_t *new_strat, int64_t *counters);
+/*
+ * Zero-copy form: the device writes the round's results straight into a pinned host block owned
+ * by the handle; *block points at it and stays valid until the next call on the handle.  With
+ * cap = *cap_out = min(sel_size, N) the block is
+ *     64 bytes reserved | int64 idx[cap] | double score[cap] | double lam_min[cap] |
+ *     double rhs[cap] | double coef[cap][coef_ld] | int32 ks[cap]
+ * of which the first *n_out entries of every array are meaningful (*block is NULL if cap = 0).
+ */
+int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld,
+                             const void **block, int64_t *cap_out, int64_t *n_out,
+                             int64_t *n_total, int32_t *new_strat, int64_t *counters);
 
 /*
  * The same round over candidate shards (one handle per GPU, SURVEY 8 e): the two device-side
@@ -221,8 +232,9 @@ int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho,
 /* Batched raw MLP forward: inputs [count][d_in] -> out [count] (the NNs.so call, batched). */
 int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs, double *out);
 
-/* Timing of the last sdpcut_score / sdpcut_rank (HIP events on the handle's stream; needs
- * SDPCUT_OPT_TIMING = 1).  ms[0] = score kernels, ms[1] = rank. */
+/* Timing of the last sdpcut_score / sdpcut_rank (HIP events on the handle's stream).
+ * SDPCUT_OPT_TIMING = 1: events around the score kernels only; = 2: also around the ranking.
+ * ms[0] = score kernels, ms[1] = rank (-1 when not recorded). */
 int sdpcut_last_timing(sdpcut_handle h, double *ms, int n);
 
 /*

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sdpcut_gather_scores_device": [_vp, _c.c_int64, _vp, _vp, _vp],
     "sdpcut_cut_rows": [_vp, _c.c_int64, _i64p, _dp, _dp, _dp, _i64p, _i32p],
     "sdpcut_select_round": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _i64p, _dp, _dp, _dp, _dp, _i32p, _i64p, _i64p, _i32p, _i64p],
+    "sdpcut_select_round_view": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
@@ -271,25 +272,36 @@ class Scorer(object):
                                               _ptr(rhs, _dp), _ptr(cols, _i64p), _ptr(ks, _i32p)))
         return lam, coef, rhs, cols, ks
 
-    def select_round(self, strat, sel_size):
+    def select_round(self, strat, sel_size, copy=True):
         """score (if needed) + rank + cut rows of the head in one call
-        -> dict(idx, score, lam, coef, rhs, ks, n_total, new_strat, counters)."""
-        cap = max(0, min(int(sel_size), self.N))
-        m = max(cap, 1)
+        -> dict(idx, score, lam, coef, rhs, ks, n_total, new_strat, counters).
+
+        The device writes the results into a pinned host block owned by the handle
+        (sdpcut_select_round_view).  copy=False returns numpy views of that block: no host copy
+        at all, valid until the next call on this Scorer; copy=True (default) detaches them."""
         ld = self.row_len
-        if getattr(self, "_round_cap", (0, 0)) != (m, ld):     # reuse the output buffers across rounds
-            self._round_bufs = (np.empty(m, dtype=np.int64), np.empty(m), np.empty(m), np.empty((m, ld)),
-                                np.empty(m), np.empty(m, dtype=np.int32))
-            self._round_cap = (m, ld)
-        idx, sc, lam, coef, rhs, ks = self._round_bufs
-        n_out, n_total, new_strat = _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
+        block, cap, n_out, n_total, new_strat = _c.c_void_p(), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
         cnt = np.zeros(4, dtype=np.int64)
-        self._check(self._lib.sdpcut_select_round(
-            self._h, int(strat), int(sel_size), ld, _ptr(idx, _i64p), _ptr(sc, _dp), _ptr(lam, _dp), _ptr(coef, _dp),
-            _ptr(rhs, _dp), _ptr(ks, _i32p), ctypes.byref(n_out), ctypes.byref(n_total), ctypes.byref(new_strat),
-            _ptr(cnt, _i64p)))
-        w = n_out.value
-        return dict(idx=idx[:w], score=sc[:w], lam=lam[:w], coef=coef[:w], rhs=rhs[:w], ks=ks[:w],
+        self._check(self._lib.sdpcut_select_round_view(
+            self._h, int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
+            ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+        w, c = int(n_out.value), int(cap.value)
+        if block.value and c:
+            nbytes = 64 + c * 8 * (4 + ld) + c * 4
+            buf = (_c.c_char * nbytes).from_address(block.value)
+            o = 64
+            idx = np.frombuffer(buf, dtype=np.int64, count=c, offset=o)[:w]; o += 8 * c
+            sc = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
+            lam = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
+            rhs = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
+            coef = np.frombuffer(buf, dtype=np.float64, count=c * ld, offset=o).reshape(c, ld)[:w]; o += 8 * c * ld
+            ks = np.frombuffer(buf, dtype=np.int32, count=c, offset=o)[:w]
+            if copy:
+                idx, sc, lam, rhs, coef, ks = (a.copy() for a in (idx, sc, lam, rhs, coef, ks))
+        else:
+            idx, sc, lam, rhs = np.empty(0, np.int64), np.empty(0), np.empty(0), np.empty(0)
+            coef, ks = np.empty((0, ld)), np.empty(0, np.int32)
+        return dict(idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks,
                     n_total=int(n_total.value), new_strat=int(new_strat.value),
                     counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]),
                                   nb_positive=int(cnt[3])))

@@ -29,6 +29,21 @@ int ensure_stage(sdpcut_ctx *h, size_t bytes)
     return 0;
 }
 
+// Pinned host block the device can also write (kernel stores = the device-to-host transfer).
+int ensure_pinned(sdpcut_ctx *h, size_t bytes)
+{
+    if (h->pinned_bytes >= bytes) return 0;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    h->pinned = nullptr;
+    h->pinned_dev = nullptr;
+    h->pinned_bytes = 0;
+    HIP_TRY(h, hipHostMalloc(&h->pinned, bytes, hipHostMallocMapped));
+    HIP_TRY(h, hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0));
+    h->pinned_bytes = bytes;
+    return 0;
+}
+
 extern "C" {
 
 int sdpcut_version(void) { return 100; }
@@ -110,7 +125,7 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         h->kernel_variant = (int)value;
         return SDPCUT_OK;
     case SDPCUT_OPT_TIMING:
-        h->timing = value != 0;
+        h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown option");
@@ -120,6 +135,7 @@ int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
 {
     if (!h) return SDPCUT_EINVAL;
     h->stream = (hip_stream == SDPCUT_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
+    h->topk_alt_clean = false;   // its zeroing was ordered on the previous stream only
     return SDPCUT_OK;
 }
 
@@ -420,11 +436,11 @@ int sdpcut_rank_device(sdpcut_handle h, int strat, int64_t sel_size, int64_t max
     if (rc) return rc;
     if (max_out < 0 || (max_out > 0 && (!d_idx_out || !d_score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
     rc = rank_on_device(h, strat, sel_size, max_out, (int64_t *)d_idx_out, (double *)d_score_out, n_written, n_total,
                         new_strat, counters);
     if (rc) return rc;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+    if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
     return SDPCUT_OK;
 }
 
@@ -527,15 +543,13 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
     return SDPCUT_OK;
 }
 
-int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, int64_t *idx_out,
-                        double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks, int64_t *n_out,
-                        int64_t *n_total, int32_t *new_strat, int64_t *counters)
+int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, const void **block,
+                             int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
 {
     if (!h) return SDPCUT_EINVAL;
     if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_STRAT_COMB)
         return sdpcut_fail(h, SDPCUT_EINVAL, "strategy must be 1 (feasibility), 2 (optimality) or 4 (combined)");
-    if (sel_size < 0 || (sel_size > 0 && (!idx_out || !score_out || !lam_min || !coef || !rhs || !ks)) || !n_out)
-        return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    if (sel_size < 0 || !block || !cap_out || !n_out) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
     if (!h->have_point || !h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
     if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD)
         return sdpcut_fail(h, SDPCUT_EINVAL, "coef_ld must hold the longest row (k + k(k+1)/2) and be <= SDPCUT_ROW_LD");
@@ -549,41 +563,37 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
     }
     int64_t cap = sel_size < h->N ? sel_size : h->N;
     *n_out = 0;
+    *cap_out = cap;
+    *block = nullptr;
     if (cap == 0)   // nothing to generate; still report the ranking's length / strategy switch
         return sdpcut_rank(h, strat, sel_size, 0, nullptr, nullptr, n_total, new_strat, counters);
-    // one device block, returned by ONE transfer: counters | idx | score | lam | rhs | coef | ks
+    // one block for everything a round returns: counters | idx | score | lam | rhs | coef | ks
     const size_t c = (size_t)cap;
     const size_t ret_bytes = 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4;
     rc = ensure_stage(h, ret_bytes + 64);
     if (rc) return rc;
-    if (h->pinned_bytes < ret_bytes) {
-        if (h->pinned) (void)hipHostFree(h->pinned);
-        h->pinned = nullptr;
-        h->pinned_bytes = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pinned, ret_bytes, hipHostMallocDefault));
-        h->pinned_bytes = ret_bytes;
-    }
+    rc = ensure_pinned(h, ret_bytes);
+    if (rc) return rc;
     char *p = (char *)h->d_stage;
-    int64_t *d_c4 = (int64_t *)p; p += 64;
+    p += 64;
     int64_t *d_idx = (int64_t *)p; p += c * 8;
     double *d_sc = (double *)p; p += c * 8;
     double *d_lam = (double *)p; p += c * 8;
     double *d_rhs = (double *)p; p += c * 8;
     double *d_coef = (double *)p; p += c * 8 * (size_t)coef_ld;
     int32_t *d_ks = (int32_t *)p;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
     int64_t w = 0;
     bool have = false;
-    // fast path: selection, rows and the transfer are enqueued back to back, one synchronisation
+    // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
+    // results directly into the pinned host block (no copy engine); one synchronisation
     const int64_t *d_cnt = nullptr;
     rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt);
     if (rc < 0) return rc;
     if (rc == 1) {
-        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
-        HIP_TRY(h, hipMemcpyAsync(d_c4, d_cnt, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
-        rc = launch_cut_rows(h, cap, d_cnt + 3, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
+        if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev);
         if (rc) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
     }
@@ -591,7 +601,7 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
         // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
         rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters);
         if (rc) return rc;
-        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
         if (w > 0) {
             rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
             if (rc) return rc;
@@ -599,9 +609,25 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }
     }
-    if (w > 0) {
-        const char *q = (const char *)h->pinned + 64;
-        const size_t ww = (size_t)w;
+    *n_out = w;
+    *block = h->pinned;
+    return SDPCUT_OK;
+}
+
+int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, int64_t *idx_out,
+                        double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks, int64_t *n_out,
+                        int64_t *n_total, int32_t *new_strat, int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (sel_size < 0 || (sel_size > 0 && (!idx_out || !score_out || !lam_min || !coef || !rhs || !ks)) || !n_out)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    const void *block = nullptr;
+    int64_t cap = 0;
+    int rc = sdpcut_select_round_view(h, strat, sel_size, coef_ld, &block, &cap, n_out, n_total, new_strat, counters);
+    if (rc) return rc;
+    if (*n_out > 0) {
+        const size_t c = (size_t)cap, ww = (size_t)*n_out;
+        const char *q = (const char *)block + 64;
         std::memcpy(idx_out, q, ww * 8); q += c * 8;
         std::memcpy(score_out, q, ww * 8); q += c * 8;
         std::memcpy(lam_min, q, ww * 8); q += c * 8;
@@ -609,7 +635,6 @@ int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t co
         std::memcpy(coef, q, ww * 8 * (size_t)coef_ld); q += c * 8 * (size_t)coef_ld;
         std::memcpy(ks, q, ww * 4);
     }
-    *n_out = w;
     return SDPCUT_OK;
 }
 

@@ -47,7 +47,7 @@ struct sdpcut_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
     int kernel_variant = SDPCUT_KERNEL_MFMA;
-    bool timing = false;
+    int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms_score = 0.f, ms_rank = 0.f;
     int n_cu = 256;
@@ -79,6 +79,8 @@ struct sdpcut_ctx {
     size_t tmp_bytes = 0;
     // top-k select workspace (topk.hip)
     void *d_topk_ws = nullptr;
+    void *d_topk_ws_alt = nullptr; // second workspace: zeroed by the epilogue of a round for the next one
+    bool topk_alt_clean = false;   // d_topk_ws_alt has been (stream-ordered) zeroed and may be swapped in
     uint64_t *d_sel_key = nullptr;
     uint32_t *d_sel_idx = nullptr;
     // triangle inequalities (tri.hip)
@@ -90,12 +92,14 @@ struct sdpcut_ctx {
     // small staging
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
-    void *pinned = nullptr;        // host staging of sdpcut_select_round (one D2H per round)
+    void *pinned = nullptr;        // host block of sdpcut_select_round (written by the device, one sync per round)
+    void *pinned_dev = nullptr;    // the same memory as the device sees it
     size_t pinned_bytes = 0;
 };
 
 int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
 int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage
+int ensure_pinned(sdpcut_ctx *h, size_t bytes);  // capi.hip: grow h->pinned / h->pinned_dev
 
 #define HIP_TRY(h, expr)                                                                   \
     do {                                                                                   \
@@ -109,6 +113,10 @@ int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage
 int launch_score(sdpcut_ctx *h, uint32_t flags);
 int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
                     double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks);
+// Epilogue of a fused round: rows of the ranking head + its ids, scores and the four counters,
+// written to `block` (device view of the pinned host block; layout of sdpcut_select_round_view).
+int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
+                      int coef_ld, void *block);
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
                      double *d_vals, double *d_vecs);
 int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);
@@ -141,3 +149,6 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[4]);
 void free_topk_ws(sdpcut_ctx *h);
+// the workspace NOT used by the selection enqueued last, and its size in 8-byte words: a later
+// kernel of the same stream may zero it and then set h->topk_alt_clean (saves the next memset)
+int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words);

@@ -761,6 +761,67 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
     }
 }
 
+// Epilogue of a fused round (sdpcut_select_round): the rows of the ranking head together with
+// its ids, scores and the four ranking counters go straight into the caller-visible block --
+// pinned host memory mapped into the device, so the stores ARE the device-to-host transfer (no
+// SDMA hand-off, no extra copy launch).  Layout (cap entries): 64 B counters | idx | score | lam |
+// rhs | coef [cap][coef_ld] | ks.  Coefficient rows are staged in LDS and leave as contiguous
+// coalesced stores.  The kernel also zeroes the top-k workspace the NEXT round will use.
+__global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64_t *d_c4, const int64_t *idx,
+                                                        const double *score, int64_t idx_base, int64_t n_local,
+                                                        const int32_t *set5, const int32_t *ks, const double *vars,
+                                                        int32_t nv, int64_t L, int coef_ld, char *block,
+                                                        uint64_t *zero_ptr, int zero_words)
+{
+    __shared__ double tile[64 * SDPCUT_ROW_LD];
+    const int lane = threadIdx.x;
+    for (int w = blockIdx.x * 64 + lane; w < zero_words; w += gridDim.x * 64) zero_ptr[w] = 0ull;
+    int64_t *o_c4 = (int64_t *)block;
+    int64_t *o_idx = (int64_t *)(block + 64);
+    double *o_score = (double *)(o_idx + cap);
+    double *o_lam = o_score + cap;
+    double *o_rhs = o_lam + cap;
+    double *o_coef = o_rhs + cap;
+    int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
+    if (blockIdx.x == 0 && lane < 4) o_c4[lane] = d_c4[lane];
+    int64_t limit = d_c4[3];
+    if (limit > cap) limit = cap;
+    const int64_t first = (int64_t)blockIdx.x * 64;
+    const int64_t i = first + lane;
+    if (i < limit) {
+        const int64_t gid = idx[i];
+        const int64_t c = gid - idx_base;
+        double co[SDPCUT_ROW_LD];
+        int64_t cl[SDPCUT_ROW_LD];
+#pragma unroll
+        for (int m = 0; m < SDPCUT_ROW_LD; ++m) co[m] = 0.0;
+        double lam = __builtin_nan(""), rhs = 0.0;
+        int k = 0;
+        if (c >= 0 && c < n_local) {
+            k = ks[c];
+            const int32_t *s5 = set5 + c * 5;
+            switch (k) {
+            case 2: cut_row_one<2>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
+            case 3: cut_row_one<3>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
+            case 4: cut_row_one<4>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
+            default: cut_row_one<5>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
+            }
+        }
+        o_idx[i] = gid;
+        o_score[i] = score[i];
+        o_lam[i] = lam;
+        o_rhs[i] = rhs;
+        o_ks[i] = k;
+#pragma unroll
+        for (int m = 0; m < SDPCUT_ROW_LD; ++m)
+            if (m < coef_ld) tile[lane * coef_ld + m] = co[m];
+    }
+    wave_lds_sync();
+    const int64_t nlive = (limit - first < 64) ? limit - first : 64;
+    const int total = nlive > 0 ? (int)nlive * coef_ld : 0;
+    for (int w = lane; w < total; w += 64) o_coef[first * coef_ld + w] = tile[w];
+}
+
 // ------------------------------------------------------------------------------------------
 // Batched full eigen-decomposition of explicit sub-matrices (twin of _get_eigendecomp).
 template <int K>
@@ -890,6 +951,22 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
                        h->N, h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
                        d_ks);
     HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
+                      int coef_ld, void *block)
+{
+    if (cap <= 0) return 0;
+    uint64_t *zp = nullptr;
+    int zw = 0;
+    int rc = topk_alt_ws(h, &zp, &zw);
+    if (rc) return rc;
+    const int grid = (int)((cap + 63) / 64);
+    hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
+                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, zp, zw);
+    HIP_TRY(h, hipGetLastError());
+    h->topk_alt_clean = true;
     return 0;
 }
 

@@ -113,13 +113,8 @@ extern "C" int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t
     const size_t ret_bytes = hdr_b + s * 8 * (4 + (size_t)coef_ld) + s * 4;
     int rc = ensure_stage(h, ret_bytes + 64);
     if (rc) return rc;
-    if (h->pinned_bytes < ret_bytes) {
-        if (h->pinned) (void)hipHostFree(h->pinned);
-        h->pinned = nullptr;
-        h->pinned_bytes = 0;
-        HIP_TRY(h, hipHostMalloc(&h->pinned, ret_bytes, hipHostMallocDefault));
-        h->pinned_bytes = ret_bytes;
-    }
+    rc = ensure_pinned(h, ret_bytes);
+    if (rc) return rc;
     char *p = (char *)h->d_stage;
     int64_t *d_hdr = (int64_t *)p; p += hdr_b;
     int64_t *d_mi = (int64_t *)p; p += s * 8;

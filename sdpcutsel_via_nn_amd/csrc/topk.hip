@@ -402,8 +402,18 @@ int ensure_topk_ws(sdpcut_ctx *h)
 
 void free_topk_ws(sdpcut_ctx *h)
 {
-    (void)hipFree(h->d_topk_ws); (void)hipFree(h->d_sel_key); (void)hipFree(h->d_sel_idx);
-    h->d_topk_ws = nullptr; h->d_sel_key = nullptr; h->d_sel_idx = nullptr;
+    (void)hipFree(h->d_topk_ws); (void)hipFree(h->d_topk_ws_alt); (void)hipFree(h->d_sel_key); (void)hipFree(h->d_sel_idx);
+    h->d_topk_ws = nullptr; h->d_topk_ws_alt = nullptr; h->d_sel_key = nullptr; h->d_sel_idx = nullptr;
+    h->topk_alt_clean = false;
+}
+
+int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words)
+{
+    static_assert(sizeof(TopkWs) % 8 == 0, "TopkWs is zeroed in 8-byte words");
+    if (!h->d_topk_ws_alt) HIP_TRY(h, hipMalloc(&h->d_topk_ws_alt, sizeof(TopkWs)));
+    *ptr = (uint64_t *)h->d_topk_ws_alt;
+    *words = (int)(sizeof(TopkWs) / 8);
+    return 0;
 }
 
 // Enqueue the selection of the head of a ranking (no host synchronisation).
@@ -418,8 +428,14 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     if (rc) return rc;
     rc = ensure_rank_ws(h, n);
     if (rc) return rc;
+    if (h->topk_alt_clean && h->d_topk_ws_alt) {
+        // the epilogue of the previous round zeroed the other workspace (stream-ordered): swap
+        void *t = h->d_topk_ws; h->d_topk_ws = h->d_topk_ws_alt; h->d_topk_ws_alt = t;
+        h->topk_alt_clean = false;
+    } else {
+        HIP_TRY(h, hipMemsetAsync(h->d_topk_ws, 0, sizeof(TopkWs), h->stream));
+    }
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
-    HIP_TRY(h, hipMemsetAsync(ws, 0, sizeof(TopkWs), h->stream));
     const double *eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;

@@ -552,4 +552,48 @@ def test_select_round_equals_separate_calls(full_c2, scorer, strat):
         assert np.array_equal(r["rhs"], rhs) and np.array_equal(r["ks"], ks)
         if ids.size:
             assert np.abs(lam - eig[ids]).max() <= 1e-15
+        # zero-copy views of the pinned block, twice (the second round runs on the workspace the
+        # first round's epilogue zeroed)
+        for _ in range(2):
+            v = scorer.select_round(strat, sel, copy=False)
+            for key in ("idx", "score", "lam", "coef", "rhs", "ks"):
+                assert np.array_equal(v[key], r[key]), key
+            assert v["counters"] == cnt and v["n_total"] == total
+        # the copying C entry point, called directly
+        import ctypes as C
+        w = len(ids)
+        o_idx, o_sc, o_lam = np.empty(sel, np.int64), np.empty(sel), np.empty(sel)
+        o_coef, o_rhs, o_ks = np.empty((sel, 9)), np.empty(sel), np.empty(sel, np.int32)
+        n_out, n_tot, ns = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        c4 = np.zeros(4, np.int64)
+        dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        rc = scorer._lib.sdpcut_select_round(
+            scorer._h, strat, sel, 9, o_idx.ctypes.data_as(lp), o_sc.ctypes.data_as(dp), o_lam.ctypes.data_as(dp),
+            o_coef.ctypes.data_as(dp), o_rhs.ctypes.data_as(dp), o_ks.ctypes.data_as(ip), C.byref(n_out), C.byref(n_tot),
+            C.byref(ns), c4.ctypes.data_as(lp))
+        assert rc == 0 and n_out.value == w and n_tot.value == total and ns.value == new_strat
+        assert np.array_equal(o_idx[:w], ids) and np.array_equal(o_coef[:w], r["coef"]) and np.array_equal(o_ks[:w], ks)
     assert scorer.select_round(strat, 0)["idx"].size == 0
+
+
+def test_select_round_general_regime(full_c2, scorer):
+    """Combined strategy with a quota above the number of strong candidates: the scan visits
+    every entry, select_round falls back to the full-sort path and still equals rank + cut_rows."""
+    wl, eig, obj = full_c2
+    scorer.set_instance(100, wl["Q_arr"])
+    strong = (obj > 0) & (eig < -1e-15)
+    m = int(np.searchsorted(np.cumsum(strong), 300)) + 1000      # a prefix holding ~300 strong candidates
+    scorer.set_candidates(wl["set_inds"][:m], wl["ks"][:m])
+    scorer.set_point(wl["vars_values"])
+    n_strong = int(strong[:m].sum())
+    sel = n_strong + 50
+    assert 0 < n_strong < sel <= m
+    r = scorer.select_round(4, sel)
+    ids, score, total, new_strat, cnt = scorer.rank(4, sel, max_out=sel)
+    lam, coef, rhs, cols, ks = scorer.cut_rows(ids)
+    assert np.array_equal(r["idx"], ids) and np.array_equal(r["score"], score)
+    assert r["new_strat"] == new_strat and r["counters"] == cnt and r["n_total"] == total
+    assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :9]) and np.array_equal(r["rhs"], rhs)
+    v = scorer.select_round(2, 100, copy=False)           # fast path again right after the fallback
+    ids2, score2, _, _, _ = scorer.rank(2, 100, max_out=100)
+    assert np.array_equal(v["idx"], ids2) and np.array_equal(v["score"], score2)
