@@ -135,7 +135,7 @@ void free_rank_ws(sdpcut_ctx *h);
 
 int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
                       double *d_score_out, const int64_t **d_c4);
-int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[4],
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[5],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out);
 
 // tri.hip
@@ -147,7 +147,7 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                         double *d_score_out, const int64_t **d_counters_out);
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                          double *d_score_out, int64_t cnt[4]);
+                          double *d_score_out, int64_t cnt[5]);
 void free_topk_ws(sdpcut_ctx *h);
 // the workspace NOT used by the selection enqueued last, and its size in 8-byte words: a later
 // kernel of the same stream may zero it and then set h->topk_alt_clean (saves the next memset)

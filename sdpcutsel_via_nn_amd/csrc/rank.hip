@@ -195,14 +195,16 @@ int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_ou
     return rc ? rc : 1;
 }
 
-// Host side of the fast path once the four counters are on the host.  Returns 1 if the enqueued
-// selection is the answer, 0 if the general path has to run (combined scan visiting everything).
-int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[4],
+// Host side of the fast path once the counters are on the host ({class size, nb_violated,
+// nb_positive, k_eff, void flag}).  Returns 1 if the enqueued selection is the answer, 0 if the
+// general path has to run (combined scan visiting everything, or a selection that gave up).
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[5],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out)
 {
     const int64_t n = h->N;
     if (sel_size > n) sel_size = n;
     const bool comb = strat == SDPCUT_STRAT_COMB;
+    if (c4[4]) return 0;
     if (comb && c4[0] < sel_size) return 0;
     const int64_t total = (strat == SDPCUT_STRAT_OPT || comb) ? n : c4[0];
     const int64_t w = total < max_out ? total : max_out;
@@ -237,8 +239,8 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         rc = rank_fast_enqueue(h, strat, sel_size, max_out, d_idx_out, d_score_out, &d_c4);
         if (rc < 0) return rc;
         if (rc == 1) {
-            int64_t c4[4] = {0, 0, 0, 0};
-            HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+            int64_t c4[5] = {0, 0, 0, 0, 0};
+            HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             if (rank_fast_finish(h, strat, sel_size, max_out, c4, n_written, n_total, new_strat, counters_out)) return 0;
             // fewer strong candidates than sel_size: every entry is visited -> general path below

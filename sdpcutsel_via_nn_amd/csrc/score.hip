@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
     double *o_rhs = o_lam + cap;
     double *o_coef = o_rhs + cap;
     int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
-    if (blockIdx.x == 0 && lane < 4) o_c4[lane] = d_c4[lane];
+    if (blockIdx.x == 0 && lane < 5) o_c4[lane] = d_c4[lane];
     int64_t limit = d_c4[3];
     if (limit > cap) limit = cap;
     const int64_t first = (int64_t)blockIdx.x * 64;

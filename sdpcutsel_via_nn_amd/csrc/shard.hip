@@ -2,7 +2,7 @@
 // RCCL all-gather of a multi-GPU round, each enqueued without host synchronisation.
 //
 //   sdpcut_shard_head_device   local head of the ranking -> one packed int64 record
-//                              [class size, nb_violated, nb_positive, k_eff, 0,0,0,0 | scores | ids]
+//                              [class size, nb_violated, nb_positive, k_eff, void, 0,0,0 | scores | ids]
 //                              (fp64 bit-cast; unused slots = (-inf, INT64_MAX)); the counters are
 //                              written by a kernel from device memory, the host never sees them here
 //   (caller)                   all_gather_into_tensor of the records (torch.distributed / RCCL)
@@ -32,6 +32,7 @@ __global__ void shard_header_kernel(int64_t *rec, const int64_t *c4, int64_t n, 
         rec[1] = c4[1];                   // nb_violated
         rec[2] = c4[2];                   // nb_positive
         rec[3] = c4[3];                   // entries actually written
+        rec[4] = c4[4];                   // != 0: the selection gave up (topk.hip), the record is void
     }
 }
 

@@ -35,12 +35,15 @@ struct TkState {
 
 struct TopkWs {
     uint32_t hist[8][256];   // [pass 0..7 = digit 7..0][bin]
-    int64_t counters[4];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
+    int64_t counters[5];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
+                             // [4] != 0: tk_hist_rest_kernel gave up waiting, the selection is void
     TkState state[9];        // state[p]: after p digits
     uint32_t done[8];        // ticket counters of the passes
     uint32_t blk_eq[TK_MAXBLK];
     uint32_t blk_gt[TK_MAXBLK];
     int64_t n_sel;           // entries compacted by tk_write_kernel (>= k_eff after an early stop)
+    uint32_t ready[9];       // tk_hist_rest_kernel: state[p] has been published inside the launch
+    uint32_t pad_[1];
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -50,6 +53,10 @@ __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
 __device__ __forceinline__ int64_t ld_i64(const int64_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_i64(int64_t *p, int64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LDS histogram update with one round of wave aggregation: in the first passes nearly every
@@ -78,8 +85,8 @@ __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
         prefix = 0;
         if (t == 0) ws->counters[3] = need;      // k_eff for the later kernels
     } else {
-        need = ws->state[p].need;                // written by the previous launch
-        prefix = ws->state[p].prefix;
+        need = ld_i64(&ws->state[p].need);       // written by the previous launch, or by another block of this one
+        prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
     }
     suf[t] = ld_u32(&ws->hist[p][t]);
     __syncthreads();
@@ -103,18 +110,18 @@ __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
             const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
             if (p < 7 && superset <= TK_MAXK) {
                 for (int qq = p + 1; qq <= 8; ++qq) {
-                    ws->state[qq].prefix = pre;
-                    ws->state[qq].need = in_bin;       // every key equal to the bin's lowest value, if any
-                    ws->state[qq].stop = 1;
+                    st_i64((int64_t *)&ws->state[qq].prefix, (int64_t)pre);
+                    st_i64(&ws->state[qq].need, in_bin);   // every key equal to the bin's lowest value, if any
+                    st_i64(&ws->state[qq].stop, 1);
                 }
             } else {
-                ws->state[p + 1].prefix = pre;
-                ws->state[p + 1].need = need - above;
+                st_i64((int64_t *)&ws->state[p + 1].prefix, (int64_t)pre);
+                st_i64(&ws->state[p + 1].need, need - above);
             }
         }
     } else if (t == 0) {
-        ws->state[p + 1].prefix = 0;
-        ws->state[p + 1].need = 0;
+        st_i64((int64_t *)&ws->state[p + 1].prefix, 0);
+        st_i64(&ws->state[p + 1].need, 0);
     }
 }
 
@@ -122,7 +129,7 @@ __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
 // Hand-off per the CDNA4 guideline: every wave drains its atomics (vmcnt(0)), workgroup barrier,
 // ONE lane does the agent-scope release and takes the ticket (a __threadfence() by all 256
 // threads of all 512 blocks cost ~30 us per pass); the last block acquires once.
-__device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist)
+__device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist, bool publish = false)
 {
     __shared__ uint32_t ticket;
     if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][threadIdx.x], hist[threadIdx.x]);
@@ -141,6 +148,14 @@ __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist)
         }
         __syncthreads();
         resolve_digit(ws, p, k);
+        if (publish) {      // grid barrier of tk_hist_rest_kernel: state[p+1] is complete
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(&ws->ready[p + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -208,6 +223,60 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
         __syncthreads();
     }
     finish_pass(ws, p, k, hist);
+}
+
+// Passes p0..7 in ONE launch.  Normally the selection was closed after one or two digits and every
+// block returns at once (one empty launch instead of six).  Otherwise (masses of equal keys) the
+// blocks run the remaining passes separated by a grid barrier: the block that resolves digit p
+// publishes ready[p+1], the others wait for it.  All TK_MAXBLK (<= 512) blocks of 256 threads are
+// resident together on the 256 CUs, and the wait is bounded anyway: when the flag does not come
+// (the GPU shared with a kernel that keeps blocks of this grid from starting) counters[4] is raised,
+// every block leaves, and the host falls back to the full-sort path.
+#define TK_SPIN_LIMIT (1 << 20)
+__global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_t n, int64_t k, const uint64_t *keys,
+                                                                  TopkWs *ws)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ int go;
+    for (int p = p0; p < 8; ++p) {
+        if (p > p0) {
+            if (threadIdx.x == 0) {
+                int ok = 1;
+                uint32_t it = 0;
+                while (__hip_atomic_load(&ws->ready[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
+                        st_i64(&ws->counters[4], 1);
+                        ok = 0;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                go = ok;
+            }
+            __syncthreads();
+            if (!go) return;
+        }
+        TkState st;
+        st.prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
+        st.need = ld_i64(&ws->state[p].need);
+        st.stop = ld_i64(&ws->state[p].stop);
+        if (st.stop || st.need < 1) return;               // uniform over the grid
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int shift = 8 * (7 - p);
+        const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
+        const int64_t rounds = (n + stride - 1) / stride;
+        for (int64_t r = 0; r < rounds; ++r) {
+            const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+            const uint64_t key = (i < n) ? keys[i] : 0ull;
+            const bool match = (i < n) && (((key ^ st.prefix) >> (shift + 8)) == 0);
+            hist_add(hist, (uint32_t)((key >> shift) & 255), match);
+        }
+        __syncthreads();
+        finish_pass(ws, p, k, hist, true);
+        __syncthreads();
+    }
 }
 
 // threshold known: per block (contiguous chunk of the index space) count the keys above it and
@@ -441,8 +510,8 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
-    for (int p = 1; p < 8; ++p)
-        hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, p, n, k, h->d_key_a, ws);
+    hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
+    hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
     int64_t chunk = (n + grid - 1) / grid;
     chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
     hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
@@ -461,12 +530,12 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
 }
 
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                          double *d_score_out, int64_t cnt[4])
+                          double *d_score_out, int64_t cnt[5])
 {
     const int64_t *d_cnt = nullptr;
     int rc = topk_select_enqueue(h, mode, k, score_add, d_idx_out, d_score_out, &d_cnt);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(cnt, d_cnt, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(cnt, d_cnt, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -197,7 +197,8 @@ class ShardedSelector(object):
             out = ops.shard_finish(self.world, sel, self._all_gather(rec), sel)
             g = out["headers"].sum(axis=0)
             length = int(g[0])
-            if strat != 4 or length >= sel:
+            # g[4] != 0: some shard's selection gave up (csrc/topk.hip), its record is void
+            if int(g[4]) == 0 and (strat != 4 or length >= sel):
                 valid = min(sel, length)
                 mine = out["ks"][:valid] > 0
                 cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))

@@ -491,6 +491,44 @@ def test_topk_select_path_equals_full_sort_full_size(full_c2, scorer, strat):
             assert np.array_equal(ids, full[0][:k]) and np.array_equal(score, full[1][:k])
 
 
+@pytest.mark.parametrize("distinct_vars", [0, 1, 12])
+def test_topk_select_with_masses_of_equal_keys_full_size(full_c2, scorer, oracle, distinct_vars):
+    """10^6 candidates at a structured point (x = 0.5, X = 0.1 everywhere except the rows of a few
+    variables): the eigenvalue takes a handful of values, each shared by 10^4..10^6 candidates, so
+    the radix select cannot close early and runs all eight digits inside tk_hist_rest_kernel's
+    grid barrier; ties are cut by index exactly as the stable sort does."""
+    from sdpcutsel_via_nn_amd import _capi
+    wl, _, _ = full_c2
+    n = 100
+    scorer.set_instance(n, wl["Q_arr"])
+    scorer.set_candidates(wl["set_inds"], wl["ks"])
+    X = np.full((n, n), 0.1)
+    for v in range(distinct_vars):
+        X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+    vv = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+    try:
+        scorer.set_point(vv)
+        scorer.score(_capi.EIG | _capi.NN)
+        eig, obj = scorer.get_scores()
+        values, counts = np.unique(eig, return_counts=True)
+        assert counts.max() > 8192 * 2 and (eig < -1e-15).all()
+        for strat in (1, 2, 4):
+            for sel, k in ((5000, 5000), (5000, 77), (8192, 8192)):
+                if strat == 4 and k > sel:
+                    continue
+                ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=k)
+                order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, sel)
+                assert np.array_equal(ids, order[:k]), (strat, sel, k)
+                assert np.array_equal(score, ref_score[:k] + 0.0)
+                assert total == order.shape[0] and new_strat == ref_strat
+            r = scorer.select_round(strat, 5000, copy=False)
+            order, ref_score, ref_strat, _ = oracle.rank_arrays(strat, obj, eig, 5000)
+            assert np.array_equal(r["idx"], order[:5000]) and np.array_equal(r["score"], ref_score[:5000] + 0.0)
+    finally:
+        scorer.set_point(wl["vars_values"])
+        scorer.score(_capi.EIG | _capi.NN)
+
+
 @pytest.mark.parametrize("tag", ["spar020_100_1_d4", "spar040_030_1_d5"])
 @pytest.mark.parametrize("point", ["mck", "rnd", "psd"])
 def test_topk_select_path_on_tie_heavy_instances(scorer, golden_boxqp, tag, point):
