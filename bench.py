@@ -26,6 +26,7 @@ N_PER_GPU = 10 ** 6
 NB_VARS = 100
 K = 3
 SEL = 5000
+PREWARM_STEPS = 150     # untimed setup before the W warmup steps (GPU clock ramp), see main()
 FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only, BASELINE.md section 4
 BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
@@ -124,6 +125,17 @@ def main():
         kernel_ms.append(sc.last_timing()[0])
         return res, rows
 
+    # Setup, untimed: the GPU comes out of idle with low clocks and needs ~50 ms of load to reach the
+    # sustained state (score kernel 0.42 -> 0.39 ms); bring it there before the W warmup steps so that
+    # short runs (K = 20) measure the same machine state as long ones.
+    # A full (generation-2) Python garbage collection walks the millions of objects `import torch`
+    # creates and stalls the host for ~75 ms once every few hundred steps: park them in the permanent
+    # generation, as latency-sensitive Python services do.
+    import gc
+    gc.collect()
+    gc.freeze()
+    for _ in range(PREWARM_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     del kernel_ms[:]

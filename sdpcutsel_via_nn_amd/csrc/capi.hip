@@ -392,10 +392,8 @@ int sdpcut_score(sdpcut_handle h, uint32_t flags)
     if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
     if (!h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates first");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
-    int rc = launch_score(h, flags);
+    int rc = launch_score(h, flags);   // with SDPCUT_OPT_TIMING the dispatches carry ev[0] / ev[1]
     if (rc) return rc;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
     h->scored |= flags;
     return SDPCUT_OK;
 }
@@ -733,8 +731,8 @@ int sdpcut_last_timing(sdpcut_handle h, double *ms, int n)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     float a = 0.f, b = 0.f;
-    if (hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess) a = -1.f;
-    if (hipEventElapsedTime(&b, h->ev[2], h->ev[3]) != hipSuccess) b = -1.f;
+    if (!h->timed_score || hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess) a = -1.f;
+    if (h->timing < 2 || hipEventElapsedTime(&b, h->ev[2], h->ev[3]) != hipSuccess) b = -1.f;
     (void)hipGetLastError();   // an unrecorded pair is not an error of this library: clear the sticky code
     ms[0] = a;
     if (n > 1) ms[1] = b;

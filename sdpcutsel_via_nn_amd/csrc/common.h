@@ -49,6 +49,7 @@ struct sdpcut_ctx {
     int kernel_variant = SDPCUT_KERNEL_MFMA;
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch
     float ms_score = 0.f, ms_rank = 0.f;
     int n_cu = 256;
 

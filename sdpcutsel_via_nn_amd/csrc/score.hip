@@ -17,6 +17,8 @@
 //
 // A second, deliberately simple kernel (lane = candidate, reference operation order, no
 // MFMA) exists for cross-checking and A/B timing (SDPCUT_KERNEL_SIMPLE).
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "jacobi.h"
 
@@ -890,8 +892,19 @@ static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
     return (int)(g < 1 ? 1 : g);
 }
 
+// With SDPCUT_OPT_TIMING the kernel's own dispatch carries the two events (hipExtLaunchKernelGGL):
+// its start / end timestamps are taken from the dispatch packet, without the two barrier packets
+// and ~20 us per step that hipEventRecord around the launch costs.
+#define SCORE_LAUNCH(kern, grid, block)                                                              \
+    do {                                                                                             \
+        if (ev_start || ev_stop)                                                                     \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, ev_start, ev_stop, 0, A); \
+        else                                                                                         \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, A);                      \
+    } while (0)
+
 template <int K>
-static int launch_score_k(sdpcut_ctx *h, uint32_t flags)
+static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const Bucket &b = h->bucket[K];
     if (b.n == 0) return 0;
@@ -912,21 +925,21 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags)
     if (h->kernel_variant == SDPCUT_KERNEL_VALU && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         const int grid = grid_for(h, ntiles, 8);
-        if (K == 2) hipLaunchKernelGGL((score_valu_kernel<2, 64, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 3) hipLaunchKernelGGL((score_valu_kernel<3, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 4) hipLaunchKernelGGL((score_valu_kernel<4, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 5) hipLaunchKernelGGL((score_valu_kernel<5, 64, 4>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 2) SCORE_LAUNCH((score_valu_kernel<2, 64, 3>), grid, 256);
+        if (K == 3) SCORE_LAUNCH((score_valu_kernel<3, 50, 3>), grid, 256);
+        if (K == 4) SCORE_LAUNCH((score_valu_kernel<4, 50, 3>), grid, 256);
+        if (K == 5) SCORE_LAUNCH((score_valu_kernel<5, 64, 4>), grid, 256);
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         const int grid = grid_for(h, ntiles, 8);
-        if (K == 2) hipLaunchKernelGGL((score_mfma_kernel<2, 64, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 3) hipLaunchKernelGGL((score_mfma_kernel<3, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 4) hipLaunchKernelGGL((score_mfma_kernel<4, 50, 3>), dim3(grid), dim3(256), 0, h->stream, A);
-        if (K == 5) hipLaunchKernelGGL((score_mfma_kernel<5, 64, 4>), dim3(grid), dim3(256), 0, h->stream, A);
+        if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3>), grid, 256);
+        if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3>), grid, 256);
+        if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3>), grid, 256);
+        if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4>), grid, 256);
     } else {
         const int64_t ntiles = (b.n + 63) / 64;
         const int grid = grid_for(h, ntiles, 16);
-        hipLaunchKernelGGL((score_simple_kernel<K>), dim3(grid), dim3(64), 0, h->stream, A);
+        SCORE_LAUNCH((score_simple_kernel<K>), grid, 64);
     }
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -934,11 +947,18 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags)
 
 int launch_score(sdpcut_ctx *h, uint32_t flags)
 {
+    // the first non-empty size class carries the start event, the last one the stop event
+    int first = 0, last = 0;
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k)
+        if (h->bucket[k].n > 0) { if (!first) first = k; last = k; }
+    h->timed_score = h->timing && first;
+    hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
+    if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
     int rc;
-    if ((rc = launch_score_k<2>(h, flags))) return rc;
-    if ((rc = launch_score_k<3>(h, flags))) return rc;
-    if ((rc = launch_score_k<4>(h, flags))) return rc;
-    if ((rc = launch_score_k<5>(h, flags))) return rc;
+    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2]))) return rc;
+    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3]))) return rc;
+    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4]))) return rc;
+    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5]))) return rc;
     return 0;
 }
 
