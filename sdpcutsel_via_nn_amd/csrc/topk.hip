@@ -22,8 +22,9 @@
 #include "keys.h"
 
 #define TK_THREADS 256
-#define TK_MAXBLK 512
+#define TK_MAXBLK 256
 #define TK_MAXK 8192
+#define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
 
 enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3 };
 
@@ -179,19 +180,31 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
     uint32_t c_class = 0, c_viol = 0, c_pos = 0;
     const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
     const int64_t rounds = (n + stride - 1) / stride;
-    for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-        const bool in = i < n;
-        uint64_t key = 0;
-        if (in) {
-            const double e = eig ? eig[i] : 0.0, o = obj ? obj[i] : 0.0;
-            key = masked_key(mode, e, o);
-            keys[i] = key;
-            c_class += (mode == TK_MODE_OPT) ? 1u : (key != 0ull);
-            c_viol += (eig != nullptr) && (e < SDPCUT_NEG_EIGVAL);
-            c_pos += (obj != nullptr) && (o > 0.0);
+    // TK_UNROLL rounds at a time with all loads issued first: a thread only has ~8 rounds, and one
+    // dependent HBM round trip per round (~2 us) was the whole cost of the pass
+    for (int64_t r0 = 0; r0 < rounds; r0 += TK_UNROLL) {
+        double e[TK_UNROLL], o[TK_UNROLL];
+        int64_t idx[TK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TK_UNROLL; ++u) {
+            idx[u] = (r0 + u) * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+            const bool in = idx[u] < n;
+            e[u] = (in && eig) ? eig[idx[u]] : 0.0;
+            o[u] = (in && obj) ? obj[idx[u]] : 0.0;
         }
-        hist_add(hist, (uint32_t)(key >> 56), in);
+#pragma unroll
+        for (int u = 0; u < TK_UNROLL; ++u) {
+            const bool in = idx[u] < n;
+            uint64_t key = 0;
+            if (in) {
+                key = masked_key(mode, e[u], o[u]);
+                keys[idx[u]] = key;
+                c_class += (mode == TK_MODE_OPT) ? 1u : (key != 0ull);
+                c_viol += (eig != nullptr) && (e[u] < SDPCUT_NEG_EIGVAL);
+                c_pos += (obj != nullptr) && (o[u] > 0.0);
+            }
+            hist_add(hist, (uint32_t)(key >> 56), in);
+        }
     }
     if (c_class) atomicAdd(&cnt[0], c_class);
     if (c_viol) atomicAdd(&cnt[1], c_viol);
@@ -214,11 +227,20 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
         const int shift = 8 * (7 - p);
         const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
         const int64_t rounds = (n + stride - 1) / stride;
-        for (int64_t r = 0; r < rounds; ++r) {
-            const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-            const uint64_t key = (i < n) ? keys[i] : 0ull;
-            const bool match = (i < n) && (((key ^ st.prefix) >> (shift + 8)) == 0);
-            hist_add(hist, (uint32_t)((key >> shift) & 255), match);
+        for (int64_t r0 = 0; r0 < rounds; r0 += TK_UNROLL) {
+            uint64_t key[TK_UNROLL];
+            bool in[TK_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = (r0 + u) * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+                in[u] = i < n;
+                key[u] = in[u] ? keys[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const bool match = in[u] && (((key[u] ^ st.prefix) >> (shift + 8)) == 0);
+                hist_add(hist, (uint32_t)((key[u] >> shift) & 255), match);
+            }
         }
         __syncthreads();
     }
@@ -267,11 +289,20 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_
         const int shift = 8 * (7 - p);
         const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
         const int64_t rounds = (n + stride - 1) / stride;
-        for (int64_t r = 0; r < rounds; ++r) {
-            const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-            const uint64_t key = (i < n) ? keys[i] : 0ull;
-            const bool match = (i < n) && (((key ^ st.prefix) >> (shift + 8)) == 0);
-            hist_add(hist, (uint32_t)((key >> shift) & 255), match);
+        for (int64_t r0 = 0; r0 < rounds; r0 += TK_UNROLL) {
+            uint64_t key[TK_UNROLL];
+            bool in[TK_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = (r0 + u) * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+                in[u] = i < n;
+                key[u] = in[u] ? keys[i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const bool match = in[u] && (((key[u] ^ st.prefix) >> (shift + 8)) == 0);
+                hist_add(hist, (uint32_t)((key[u] >> shift) & 255), match);
+            }
         }
         __syncthreads();
         finish_pass(ws, p, k, hist, true);
@@ -429,9 +460,21 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
     const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
     if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
     const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
-    for (int j = threadIdx.x; j < ntiles * TK_TILE; j += TK_THREADS) {
-        sk[j] = tile_key[j];
-        si[j] = tile_idx[j];
+    for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 8 * TK_THREADS) {      // 8 loads in flight per thread
+        uint64_t kk[8];
+        uint32_t ii[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * TK_THREADS + threadIdx.x;
+            const bool in = j < ntiles * TK_TILE;
+            kk[u] = in ? tile_key[j] : 0ull;
+            ii[u] = in ? tile_idx[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * TK_THREADS + threadIdx.x;
+            if (j < ntiles * TK_TILE) { sk[j] = kk[u]; si[j] = ii[u]; }
+        }
     }
     __syncthreads();
     const int e = blockIdx.x * TK_THREADS + threadIdx.x;      // position in the tiled array
