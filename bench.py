@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     args = ap.parse_args()
 
@@ -100,6 +101,8 @@ def main():
         wl["Q_arr"], wl["vars_values"] = wl0[0], wl0[1]
     sc = _capi.Scorer(local_rank)
     sc.set_option(_capi.OPT_TIMING, 1)
+    if args.fuse:
+        sc.set_option(_capi.OPT_FUSE_KEYS, 1)
     sc.set_option(_capi.OPT_KERNEL, {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[args.kernel])
     sc.set_network(K, *networks.load_network(K))
     sc.set_instance(NB_VARS, wl["Q_arr"])
@@ -173,7 +176,7 @@ def main():
                        "kernel": args.kernel, "strategy": 4},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": {"mfma": "score_mfma_kernel<3,50,3>", "valu": "score_valu_kernel<3,50,3>", "simple": "score_simple_kernel<3>"}[args.kernel],
+                         "kernel": {"mfma": "score_mfma_kernel<3, 50, 3, %s>" % ("true" if args.fuse else "false"), "valu": "score_valu_kernel<3,50,3>", "simple": "score_simple_kernel<3>"}[args.kernel],
                          "kernel_ms": k_ms, "flops_per_candidate": FLOPS_PER_CAND[K],
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                          "bytes_per_candidate": BYTES_PER_CAND[K]},

@@ -54,7 +54,12 @@ enum { SDPCUT_PART_STRONG = 104 };
 
 /* kernel variants for sdpcut_set_option(SDPCUT_OPT_KERNEL, ...) */
 enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 };
-enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2 };
+/* SDPCUT_OPT_FUSE_KEYS = 1: sdpcut_select_round lets the score kernels run the first pass of the
+ * top-k selection (keys, leading-digit histogram, class counters) instead of a separate pass
+ * over the scores.  Default 0: on MI355X the two variants take the same time per round (the
+ * separate pass costs 16 us, the fused epilogue 15 us), and the unfused score kernel is the
+ * cleaner unit to measure. */
+enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3 };
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
 #define SDPCUT_MAX_K 5

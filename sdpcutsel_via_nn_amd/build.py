@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdpcut_hip.so")
 SOURCES = ["score.hip", "rank.hip", "topk.hip", "tri.hip", "shard.hip", "capi.hip", "cover.cpp"]
-HEADERS = ["common.h", "jacobi.h", "keys.h", os.path.join("..", "..", "include", "sdpcut.h")]
+HEADERS = ["common.h", "jacobi.h", "keys.h", "topk_dev.h", os.path.join("..", "..", "include", "sdpcut.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-unused-value"]

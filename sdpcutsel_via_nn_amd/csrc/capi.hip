@@ -124,6 +124,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
             return sdpcut_fail(h, SDPCUT_EINVAL, "unknown kernel variant");
         h->kernel_variant = (int)value;
         return SDPCUT_OK;
+    case SDPCUT_OPT_FUSE_KEYS:
+        h->fuse_keys = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
@@ -555,11 +558,23 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
                           : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
     int rc;
-    if ((h->scored & need) != need) {
+    int64_t cap = sel_size < h->N ? sel_size : h->N;
+    bool keys_done = false;
+    if (h->fuse_keys && (h->scored & need) == 0 && rank_fast_mode(h, strat, sel_size, cap, nullptr)) {
+        // nothing scored at this point yet and the head comes from the radix select: let the score
+        // kernels run the selection's first pass (keys, leading digit, class counters) as well
+        ScoreFuse fuse;
+        fuse.mode = rank_fast_mode(h, strat, sel_size, cap, nullptr);
+        fuse.k = cap;
+        rc = topk_begin(h, &fuse.ws, &fuse.keys);
+        if (rc) return rc;
+        rc = launch_score(h, need, &fuse, &keys_done);
+        if (rc) return rc;
+        h->scored |= need;
+    } else if ((h->scored & need) != need) {
         rc = sdpcut_score(h, need & ~h->scored);
         if (rc) return rc;
     }
-    int64_t cap = sel_size < h->N ? sel_size : h->N;
     *n_out = 0;
     *cap_out = cap;
     *block = nullptr;
@@ -586,7 +601,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
     // results directly into the pinned host block (no copy engine); one synchronisation
     const int64_t *d_cnt = nullptr;
-    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt);
+    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, keys_done);
     if (rc < 0) return rc;
     if (rc == 1) {
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));

@@ -47,6 +47,7 @@ struct sdpcut_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
     int kernel_variant = SDPCUT_KERNEL_MFMA;
+    bool fuse_keys = false;        // SDPCUT_OPT_FUSE_KEYS (measured: no gain, see include/sdpcut.h)
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch
@@ -111,7 +112,15 @@ int ensure_pinned(sdpcut_ctx *h, size_t bytes);  // capi.hip: grow h->pinned / h
     } while (0)
 
 // score.hip
-int launch_score(sdpcut_ctx *h, uint32_t flags);
+// Optional fusion of the top-k selection's first pass into the score kernels (ScoreArgs::tk):
+// ws = zeroed TopkWs of the selection that follows, keys = its key array [N].
+struct ScoreFuse {
+    void *ws;
+    uint64_t *keys;
+    int mode;      // TK_MODE_* of topk_dev.h
+    int64_t k;     // head length asked from the selection
+};
+int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse = nullptr, bool *fused = nullptr);
 int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
                     double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks);
 // Epilogue of a fused round: rows of the ranking head + its ids, scores and the four counters,
@@ -135,7 +144,9 @@ int rank_fetch_on_device(sdpcut_ctx *h, int64_t offset, int64_t count, int64_t *
 void free_rank_ws(sdpcut_ctx *h);
 
 int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
-                      double *d_score_out, const int64_t **d_c4);
+                      double *d_score_out, const int64_t **d_c4, bool keys_done = false);
+// TK_MODE_* the fast path would use for this request, 0 if it is not eligible
+int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, double *score_add);
 int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[5],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out);
 
@@ -146,7 +157,11 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
 
 // topk.hip
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                        double *d_score_out, const int64_t **d_counters_out);
+                        double *d_score_out, const int64_t **d_counters_out, bool keys_done = false);
+// allocate / zero (or swap in the pre-zeroed) workspace of the next selection and return it together
+// with the key array: what a score launch needs to run the selection's first pass itself
+// (ScoreFuse); follow with topk_select_enqueue(..., keys_done = true)
+int topk_begin(sdpcut_ctx *h, void **ws, uint64_t **keys);
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[5]);
 void free_topk_ws(sdpcut_ctx *h);

@@ -171,27 +171,33 @@ static inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
 // entries, _SDP_CUTS_PER_ROUND_MAX): radix select + small sort instead of sorting all N.
 // Returns 1 if the selection has been enqueued (no host synchronisation), 0 if the request is
 // not eligible, < 0 on error.  *d_c4 = device address of {class size, nb_violated, nb_positive, k_eff}.
-int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
-                      double *d_score_out, const int64_t **d_c4)
+int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, double *score_add)
 {
     const int64_t n = h->N;
     if (sel_size > n) sel_size = n;
+    if (score_add) *score_add = 0.0;
     if (!(n > 0 && max_out >= 1 && max_out <= 8192)) return 0;
-    int mode = 0;
-    double add = 0.0;
-    if (strat == SDPCUT_STRAT_FEAS) mode = 1;
-    else if (strat == SDPCUT_STRAT_OPT) mode = 2;
-    else if (strat == SDPCUT_PART_STRONG) mode = 3;
-    else if (strat == SDPCUT_STRAT_COMB && sel_size >= 1 && max_out <= sel_size) {
+    if (strat == SDPCUT_STRAT_FEAS) return 1;
+    if (strat == SDPCUT_STRAT_OPT) return 2;
+    if (strat == SDPCUT_PART_STRONG) return 3;
+    if (strat == SDPCUT_STRAT_COMB && sel_size >= 1 && max_out <= sel_size) {
         // combined scan, common regime: at least sel_size candidates are positive AND violated.
         // The scan stops after sel_size of them; the re-sorted list starts with exactly those,
         // +BIG_M, in obj_improve order (cut_select_qp.py:606-625).  rank_fast_finish verifies
         // the regime through the class size.
-        mode = 3;
-        add = SDPCUT_BIG_M;
+        if (score_add) *score_add = SDPCUT_BIG_M;
+        return 3;
     }
+    return 0;
+}
+
+int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
+                      double *d_score_out, const int64_t **d_c4, bool keys_done)
+{
+    double add = 0.0;
+    const int mode = rank_fast_mode(h, strat, sel_size, max_out, &add);
     if (!mode) return 0;
-    int rc = topk_select_enqueue(h, mode, max_out, add, d_idx_out, d_score_out, d_c4);
+    int rc = topk_select_enqueue(h, mode, max_out, add, d_idx_out, d_score_out, d_c4, keys_done);
     return rc ? rc : 1;
 }
 

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "jacobi.h"
+#include "topk_dev.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -35,6 +36,14 @@ struct ScoreArgs {
     double *eig_out;      // [N] caller order
     double *obj_out;      // [N]
     uint32_t flags;
+    // Fused first pass of the top-k selection (topk_dev.h; tk == nullptr: off): the kernel that
+    // produces the scores also writes their radix keys, the histogram of the leading digit and the
+    // class counters, which saves the separate key pass over 24 MB (tk_keys_kernel, ~16 us).
+    TopkWs *tk;
+    uint64_t *tk_keys;     // [N] caller order
+    int tk_mode;
+    int64_t tk_k;
+    uint32_t tk_blocks;    // blocks of ALL score launches of this call (ticket target of the pass)
     NetDev net;
 };
 
@@ -262,8 +271,9 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #endif
 
 // ------------------------------------------------------------------------------------------
-// MFMA kernel.  K candidate size, H hidden width, NH hidden layers.
-template <int K, int H, int NH>
+// MFMA kernel.  K candidate size, H hidden width, NH hidden layers; FUSE: also run the first pass
+// of the top-k selection (ScoreArgs::tk).
+template <int K, int H, int NH, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 {
     constexpr int M = K * (K + 1) / 2;
@@ -289,6 +299,16 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     const NetDev &net = A.net;
     const int64_t ntiles = (A.n + 255) / 256;
 
+    // fused first pass of the top-k selection (A.tk != nullptr)
+    __shared__ uint32_t tk_hist[256];
+    __shared__ uint32_t tk_cnt[3];
+    uint32_t c_class = 0, c_viol = 0, c_pos = 0;
+    if constexpr (FUSE) {
+        tk_hist[threadIdx.x] = 0;
+        if (threadIdx.x < 3) tk_cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t c = tile * 256 + threadIdx.x;
         const bool valid = c < A.n;
@@ -297,11 +317,24 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
         const int32_t out_idx = A.orig[cc];
 
+        double lam = 0.0;
         if (A.flags & SDPCUT_EIG) {
-            const double lam = candidate_eigmin<K>(cd);
+            lam = candidate_eigmin<K>(cd);
             if (valid) A.eig_out[out_idx] = lam;
         }
-        if (!(A.flags & SDPCUT_NN)) continue;   // uniform branch
+        if (!(A.flags & SDPCUT_NN)) {           // uniform branch
+            if constexpr (FUSE) {
+                uint64_t key = 0;
+                if (valid) {
+                    key = masked_key(A.tk_mode, lam, 0.0);
+                    A.tk_keys[out_idx] = key;
+                    c_class += (A.tk_mode == TK_MODE_OPT) ? 1u : (key != 0ull);
+                    c_viol += lam < SDPCUT_NEG_EIGVAL;
+                }
+                hist_add(tk_hist, (uint32_t)(key >> 56), valid);
+            }
+            continue;
+        }
 
         // ---- stage mapminmax'ed inputs (neural_net_3D.m:69-73): xp = (v - xoffset)*gain + ymin
 #pragma unroll
@@ -442,8 +475,29 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             double obj = cd.negSM;
             obj = obj + y * cd.max_elem;
             if (valid) A.obj_out[out_idx] = obj;
+            if constexpr (FUSE) {
+                const bool have_eig = (A.flags & SDPCUT_EIG) != 0;
+                uint64_t key = 0;
+                if (valid) {
+                    key = masked_key(A.tk_mode, lam, obj);
+                    A.tk_keys[out_idx] = key;
+                    c_class += (A.tk_mode == TK_MODE_OPT) ? 1u : (key != 0ull);
+                    c_viol += have_eig && (lam < SDPCUT_NEG_EIGVAL);
+                    c_pos += obj > 0.0;
+                }
+                hist_add(tk_hist, (uint32_t)(key >> 56), valid);
+            }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
+    }
+    if constexpr (FUSE) {   // same tail as tk_keys_kernel: class counters, then the pass hand-off
+        if (c_class) atomicAdd(&tk_cnt[0], c_class);
+        if (c_viol) atomicAdd(&tk_cnt[1], c_viol);
+        if (c_pos) atomicAdd(&tk_cnt[2], c_pos);
+        __syncthreads();
+        if (threadIdx.x < 3 && tk_cnt[threadIdx.x])
+            atomicAdd((unsigned long long *)&A.tk->counters[threadIdx.x], (unsigned long long)tk_cnt[threadIdx.x]);
+        finish_pass(A.tk, 0, A.tk_k, tk_hist, A.tk_blocks);
     }
 }
 
@@ -903,8 +957,19 @@ static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, A);                      \
     } while (0)
 
+// does size class K run on the MFMA / VALU kernels (network shape they are instantiated for)?
+static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
+{
+    if (!(flags & SDPCUT_NN)) return true;   // eig only: the network part of the kernel is skipped
+    if (!h->net[K].set) return false;
+    const NetDev &nd = h->net[K].dev;
+    return (K == 2 && nd.width == 64 && nd.n_hidden == 3) || (K == 3 && nd.width == 50 && nd.n_hidden == 3) ||
+           (K == 4 && nd.width == 50 && nd.n_hidden == 3) || (K == 5 && nd.width == 64 && nd.n_hidden == 4);
+}
+
 template <int K>
-static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop)
+static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
+                          const ScoreFuse *fuse, uint32_t fuse_blocks)
 {
     const Bucket &b = h->bucket[K];
     if (b.n == 0) return 0;
@@ -912,16 +977,15 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
     A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
+    A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
+    A.tk_keys = fuse ? fuse->keys : nullptr;
+    A.tk_mode = fuse ? fuse->mode : 0;
+    A.tk_k = fuse ? fuse->k : 0;
+    A.tk_blocks = fuse_blocks;
     A.net = h->net[K].dev;
-    const NetDev &nd = A.net;
-    bool mfma_ok = false;
-    if (flags & SDPCUT_NN) {
-        if (!h->net[K].set) return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
-        mfma_ok = (K == 2 && nd.width == 64 && nd.n_hidden == 3) || (K == 3 && nd.width == 50 && nd.n_hidden == 3) ||
-                  (K == 4 && nd.width == 50 && nd.n_hidden == 3) || (K == 5 && nd.width == 64 && nd.n_hidden == 4);
-    } else {
-        mfma_ok = true;   // eig only: the network part of the kernel is skipped
-    }
+    if ((flags & SDPCUT_NN) && !h->net[K].set)
+        return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
+    const bool mfma_ok = net_shape_ok(h, K, flags);
     if (h->kernel_variant == SDPCUT_KERNEL_VALU && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         const int grid = grid_for(h, ntiles, 8);
@@ -932,10 +996,17 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         const int grid = grid_for(h, ntiles, 8);
-        if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3>), grid, 256);
-        if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3>), grid, 256);
-        if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3>), grid, 256);
-        if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4>), grid, 256);
+        if (A.tk) {
+            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true>), grid, 256);
+            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
+            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true>), grid, 256);
+            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, true>), grid, 256);
+        } else {
+            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3>), grid, 256);
+            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3>), grid, 256);
+            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3>), grid, 256);
+            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4>), grid, 256);
+        }
     } else {
         const int64_t ntiles = (b.n + 63) / 64;
         const int grid = grid_for(h, ntiles, 16);
@@ -945,8 +1016,22 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     return 0;
 }
 
-int launch_score(sdpcut_ctx *h, uint32_t flags)
+int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused)
 {
+    // the fused key pass lives in the MFMA kernel only: every non-empty size class must run on it;
+    // the last block over ALL launches resolves the digit, so it needs the total block count
+    uint32_t fuse_blocks = 0;
+    if (fused) *fused = false;
+    if (fuse) {
+        bool ok = h->kernel_variant == SDPCUT_KERNEL_MFMA;
+        for (int k = 2; k <= SDPCUT_MAX_K && ok; ++k) {
+            if (h->bucket[k].n == 0) continue;
+            ok = net_shape_ok(h, k, flags);
+            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, 8);
+        }
+        if (!ok || fuse_blocks == 0) fuse = nullptr;
+        else if (fused) *fused = true;
+    }
     // the first non-empty size class carries the start event, the last one the stop event
     int first = 0, last = 0;
     for (int k = 2; k <= SDPCUT_MAX_K; ++k)
@@ -955,10 +1040,10 @@ int launch_score(sdpcut_ctx *h, uint32_t flags)
     hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
     if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
     int rc;
-    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2]))) return rc;
-    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3]))) return rc;
-    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4]))) return rc;
-    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5]))) return rc;
+    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, fuse_blocks))) return rc;
+    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, fuse_blocks))) return rc;
+    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, fuse_blocks))) return rc;
+    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, fuse_blocks))) return rc;
     return 0;
 }
 

@@ -18,155 +18,8 @@
 // the release/acquire.  Histogram cells and counters are written with device-scope atomics
 // and read back by the resolving block with device-scope atomic loads (per-XCD L2s are not
 // coherent for plain loads inside a launch).
-#include "common.h"
-#include "keys.h"
 
-#define TK_THREADS 256
-#define TK_MAXBLK 256
-#define TK_MAXK 8192
-#define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
-
-enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3 };
-
-struct TkState {
-    uint64_t prefix;   // digits resolved so far, in place
-    int64_t need;      // how many of the keys matching the prefix are still wanted (0: nothing)
-    int64_t stop;      // 1: the selection was closed early (see resolve_digit), later passes are no-ops
-};
-
-struct TopkWs {
-    uint32_t hist[8][256];   // [pass 0..7 = digit 7..0][bin]
-    int64_t counters[5];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
-                             // [4] != 0: tk_hist_rest_kernel gave up waiting, the selection is void
-    TkState state[9];        // state[p]: after p digits
-    uint32_t done[8];        // ticket counters of the passes
-    uint32_t blk_eq[TK_MAXBLK];
-    uint32_t blk_gt[TK_MAXBLK];
-    int64_t n_sel;           // entries compacted by tk_write_kernel (>= k_eff after an early stop)
-    uint32_t ready[9];       // tk_hist_rest_kernel: state[p] has been published inside the launch
-    uint32_t pad_[1];
-};
-
-__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int64_t ld_i64(const int64_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_i64(int64_t *p, int64_t v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// LDS histogram update with one round of wave aggregation: in the first passes nearly every
-// key of a wave falls into the same bin, and 64 same-address LDS atomics would serialise.
-__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool active)
-{
-    const unsigned long long act = __ballot(active);
-    if (!act) return;
-    const int leader = __ffsll((long long)act) - 1;
-    const uint32_t lead_bin = (uint32_t)__shfl((int)bin, leader);
-    const unsigned long long same = __ballot(active && bin == lead_bin);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lead_bin], (uint32_t)__popcll(same));
-    if (active && bin != lead_bin) atomicAdd(&hist[bin], 1u);
-}
-
-// Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].
-__device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
-{
-    __shared__ uint32_t suf[TK_THREADS];
-    const int t = threadIdx.x;
-    int64_t need;
-    uint64_t prefix;
-    if (p == 0) {
-        const int64_t cls = ld_i64(&ws->counters[0]);
-        need = k < cls ? k : cls;
-        prefix = 0;
-        if (t == 0) ws->counters[3] = need;      // k_eff for the later kernels
-    } else {
-        need = ld_i64(&ws->state[p].need);       // written by the previous launch, or by another block of this one
-        prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
-    }
-    suf[t] = ld_u32(&ws->hist[p][t]);
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {     // suffix sums S[t] = sum_{b >= t} hist[b]
-        const uint32_t v = (t + off < 256) ? suf[t + off] : 0u;
-        __syncthreads();
-        suf[t] += v;
-        __syncthreads();
-    }
-    const int64_t here = suf[t], above = (t < 255) ? suf[t + 1] : 0;
-    if (need >= 1) {
-        if (here >= need && above < need) {       // exactly one bin
-            const uint64_t pre = prefix | ((uint64_t)t << (8 * (7 - p)));
-            // Early stop: the keys above this bin (k_eff - (need - above) of them) plus the WHOLE bin
-            // fit the sort buffers, so take that superset -- every key >= the bin's lowest value --
-            // and let the final sort put the wanted k_eff first.  With 10^6 spread-out scores this
-            // happens after 2-3 digits; masses of equal keys keep the passes going to the last digit,
-            // where ties are cut by index as before.
-            const int64_t k_eff = ld_i64(&ws->counters[3]);
-            const int64_t in_bin = here - above;
-            const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
-            if (p < 7 && superset <= TK_MAXK) {
-                for (int qq = p + 1; qq <= 8; ++qq) {
-                    st_i64((int64_t *)&ws->state[qq].prefix, (int64_t)pre);
-                    st_i64(&ws->state[qq].need, in_bin);   // every key equal to the bin's lowest value, if any
-                    st_i64(&ws->state[qq].stop, 1);
-                }
-            } else {
-                st_i64((int64_t *)&ws->state[p + 1].prefix, (int64_t)pre);
-                st_i64(&ws->state[p + 1].need, need - above);
-            }
-        }
-    } else if (t == 0) {
-        st_i64((int64_t *)&ws->state[p + 1].prefix, 0);
-        st_i64(&ws->state[p + 1].need, 0);
-    }
-}
-
-// publish this block's LDS histogram; the last block to arrive resolves the digit.
-// Hand-off per the CDNA4 guideline: every wave drains its atomics (vmcnt(0)), workgroup barrier,
-// ONE lane does the agent-scope release and takes the ticket (a __threadfence() by all 256
-// threads of all 512 blocks cost ~30 us per pass); the last block acquires once.
-__device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist, bool publish = false)
-{
-    __shared__ uint32_t ticket;
-    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][threadIdx.x], hist[threadIdx.x]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ticket = __hip_atomic_fetch_add(&ws->done[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (ticket == gridDim.x - 1) {
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        resolve_digit(ws, p, k);
-        if (publish) {      // grid barrier of tk_hist_rest_kernel: state[p+1] is complete
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(&ws->ready[p + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
-{
-    if (mode == TK_MODE_OPT) return key_of(obj);
-    const bool viol = eig < SDPCUT_NEG_EIGVAL;
-    if (mode == TK_MODE_FEAS) return viol ? key_of(-eig) : 0ull;
-    return (obj > 0.0 && viol) ? key_of(obj) : 0ull;
-}
+#include "topk_dev.h"
 
 // pass 0: build the keys, histogram of digit 7, class / violated / positive counts
 __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n, int64_t k, const double *eig,
@@ -212,7 +65,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
     __syncthreads();
     if (threadIdx.x < 3 && cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&ws->counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
-    finish_pass(ws, 0, k, hist);
+    finish_pass(ws, 0, k, hist, gridDim.x);
 }
 
 // pass p = 1..7: histogram of digit 7-p among the keys that match the prefix resolved so far
@@ -244,7 +97,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
         }
         __syncthreads();
     }
-    finish_pass(ws, p, k, hist);
+    finish_pass(ws, p, k, hist, gridDim.x);
 }
 
 // Passes p0..7 in ONE launch.  Normally the selection was closed after one or two digits and every
@@ -305,7 +158,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_
             }
         }
         __syncthreads();
-        finish_pass(ws, p, k, hist, true);
+        finish_pass(ws, p, k, hist, gridDim.x, true);
         __syncthreads();
     }
 }
@@ -531,14 +384,11 @@ int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words)
 // Enqueue the selection of the head of a ranking (no host synchronisation).
 // mode: 1 feasibility, 2 optimality, 3 strong class.  min(k, class size) entries are written.
 // *d_counters_out receives the device address of {class size, nb_violated, nb_positive, k_eff}.
-int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                        double *d_score_out, const int64_t **d_counters_out)
+int topk_begin(sdpcut_ctx *h, void **ws_out, uint64_t **keys_out)
 {
-    const int64_t n = h->N;
-    if (k < 1 || k > TK_MAXK || n < 1) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k out of range");
     int rc = ensure_topk_ws(h);
     if (rc) return rc;
-    rc = ensure_rank_ws(h, n);
+    rc = ensure_rank_ws(h, h->N);
     if (rc) return rc;
     if (h->topk_alt_clean && h->d_topk_ws_alt) {
         // the epilogue of the previous round zeroed the other workspace (stream-ordered): swap
@@ -547,12 +397,30 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     } else {
         HIP_TRY(h, hipMemsetAsync(h->d_topk_ws, 0, sizeof(TopkWs), h->stream));
     }
+    if (ws_out) *ws_out = h->d_topk_ws;
+    if (keys_out) *keys_out = h->d_key_a;
+    return 0;
+}
+
+// keys_done: the score kernels already ran pass 0 (keys, leading digit, class counters) on the
+// workspace handed out by topk_begin.
+int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
+                        double *d_score_out, const int64_t **d_counters_out, bool keys_done)
+{
+    const int64_t n = h->N;
+    if (k < 1 || k > TK_MAXK || n < 1) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k out of range");
+    int rc = 0;
+    if (!keys_done) {
+        rc = topk_begin(h, nullptr, nullptr);
+        if (rc) return rc;
+    }
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
     const double *eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
-    hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
+    if (!keys_done)
+        hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
     hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
     hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
     int64_t chunk = (n + grid - 1) / grid;
