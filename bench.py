@@ -75,6 +75,9 @@ def main():
     # rehearsal knobs (one-GPU box): SDPCUT_BENCH_BACKEND=gloo stages the all-gather through the
     # host, SDPCUT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
     backend = os.environ.get("SDPCUT_BENCH_BACKEND", "nccl")
+    # SDPCUT_BENCH_FORCE_SHARDED=1: run the N > 1 code path (packed head, finish) at N = 1 to see
+    # what it costs over the fused single-GPU round, the collective itself excluded
+    force_sharded = os.environ.get("SDPCUT_BENCH_FORCE_SHARDED") == "1"
     if os.environ.get("SDPCUT_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -108,15 +111,18 @@ def main():
     sc.set_instance(NB_VARS, wl["Q_arr"])
     sc.set_candidates(wl["set_inds"], wl["ks"], global_base=rank * N_PER_GPU)
     d_vars = torch.from_numpy(wl["vars_values"]).to(device)
-    ops = DeviceOps(sc, device)
-    sel = ShardedSelector(ops, N_PER_GPU)
-    lo, hi = rank * N_PER_GPU, (rank + 1) * N_PER_GPU
+    sel = None
+    if world > 1 or force_sharded:
+        # DeviceOps binds the library to torch's current stream: its kernels, torch's copies and the
+        # hand-off to the collective are ordered without host synchronisation (a dedicated
+        # non-blocking stream measured no better at N = 1 and worse with two ranks on one GPU)
+        sel = ShardedSelector(DeviceOps(sc, device), N_PER_GPU)
 
     kernel_ms = []
 
     def step():
         sc.set_point_device(d_vars.data_ptr())
-        if world == 1:
+        if world == 1 and not force_sharded:
             # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> one D2H
             # (results land in the handle's pinned host block; copy=False hands out views of it)
             res = rows = sc.select_round(4, SEL, copy=False)

@@ -208,7 +208,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
  * sdpcut_shard_head_device: enqueue, WITHOUT host synchronisation, this shard's head of the
  * ranking (strat 1, 2 or SDPCUT_PART_STRONG) into one packed device record of 8 + 2*count
  * int64 words
- *     [list length, nb_violated, nb_positive, entries written, 0, 0, 0, 0 |
+ *     [list length, nb_violated, nb_positive, entries written, void flag, 0, 0, 0 |
  *      count scores (fp64 bits) | count GLOBAL ids]
  * padded with (-inf, INT64_MAX); 1 <= count <= 8192.
  *
@@ -224,6 +224,14 @@ int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count,
                               const void *d_allrec, int64_t sel_size, int32_t coef_ld,
                               int64_t *headers_out, int64_t *idx_out, double *score_out,
                               double *lam_min, double *coef, double *rhs, int32_t *ks);
+/* Zero-copy form (see sdpcut_select_round_view): *block = the handle's pinned host block
+ *     int64 headers[world][8] | int64 idx[sel_size] | double score[sel_size] |
+ *     double lam_min[sel_size] | double rhs[sel_size] | double coef[sel_size][coef_ld] |
+ *     int32 ks[sel_size]
+ * written by the device, valid until the next call on the handle. */
+int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, int64_t count,
+                                   const void *d_allrec, int64_t sel_size, int32_t coef_ld,
+                                   const void **block);
 
 /*
  * Batched twin of _get_eigendecomp (cut_select_qp.py:788-797) for explicit sub-matrices:

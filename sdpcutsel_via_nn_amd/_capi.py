@@ -52,6 +52,7 @@ SIGNATURES = {
     "sdpcut_select_round_view": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
+    "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
     "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
@@ -311,20 +312,27 @@ class Scorer(object):
         """enqueue this shard's packed head record (8 + 2*count int64 words); no host sync"""
         self._check(self._lib.sdpcut_shard_head_device(self._h, int(strat), int(count), _vp(d_record_ptr)))
 
-    def shard_finish_round(self, world, count, d_allrec_ptr, sel_size):
+    def shard_finish_round(self, world, count, d_allrec_ptr, sel_size, copy=False):
         """merge the gathered records, cut rows of this shard's entries
-        -> dict(headers [world, 8], idx, score, lam, coef, rhs, ks), each of sel_size entries"""
-        m, ld = int(sel_size), self.row_len
-        key = (int(world), m, ld)
-        if getattr(self, "_shard_cap", None) != key:
-            self._shard_bufs = (np.empty((int(world), 8), dtype=np.int64), np.empty(m, dtype=np.int64), np.empty(m),
-                                np.empty(m), np.empty((m, ld)), np.empty(m), np.empty(m, dtype=np.int32))
-            self._shard_cap = key
-        hdr, idx, sc, lam, coef, rhs, ks = self._shard_bufs
-        self._check(self._lib.sdpcut_shard_finish_round(
-            self._h, int(world), int(count), _vp(d_allrec_ptr), m, ld, _ptr(hdr, _i64p), _ptr(idx, _i64p),
-            _ptr(sc, _dp), _ptr(lam, _dp), _ptr(coef, _dp), _ptr(rhs, _dp), _ptr(ks, _i32p)))
-        return dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks)
+        -> dict(headers [world, 8], idx, score, lam, coef, rhs, ks), each of sel_size entries:
+        numpy views of the handle's pinned host block, which the device wrote directly
+        (valid until the next call on this Scorer; copy=True detaches them)"""
+        m, ld, w = int(sel_size), self.row_len, int(world)
+        block = _c.c_void_p()
+        self._check(self._lib.sdpcut_shard_finish_round_view(
+            self._h, w, int(count), _vp(d_allrec_ptr), m, ld, ctypes.byref(block)))
+        nbytes = w * 64 + m * 8 * (4 + ld) + m * 4
+        buf = (_c.c_char * nbytes).from_address(block.value)
+        o = 0
+        hdr = np.frombuffer(buf, dtype=np.int64, count=w * 8, offset=o).reshape(w, 8); o += w * 64
+        idx = np.frombuffer(buf, dtype=np.int64, count=m, offset=o); o += 8 * m
+        sc = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+        lam = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+        rhs = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+        coef = np.frombuffer(buf, dtype=np.float64, count=m * ld, offset=o).reshape(m, ld); o += 8 * m * ld
+        ks = np.frombuffer(buf, dtype=np.int32, count=m, offset=o)
+        out = dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks)
+        return {k: v.copy() for k, v in out.items()} if copy else out
 
     # ------------------------------------------------------------------ triangle inequalities
     def tri_preprocess(self, adjacency):

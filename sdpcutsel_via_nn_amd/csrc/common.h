@@ -126,7 +126,7 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
 // Epilogue of a fused round: rows of the ranking head + its ids, scores and the four counters,
 // written to `block` (device view of the pinned host block; layout of sdpcut_select_round_view).
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
-                      int coef_ld, void *block);
+                      int coef_ld, void *block, int64_t hdr_bytes = 64);
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
                      double *d_vals, double *d_vecs);
 int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);

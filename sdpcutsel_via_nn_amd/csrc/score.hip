@@ -823,25 +823,30 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
 // SDMA hand-off, no extra copy launch).  Layout (cap entries): 64 B counters | idx | score | lam |
 // rhs | coef [cap][coef_ld] | ks.  Coefficient rows are staged in LDS and leave as contiguous
 // coalesced stores.  The kernel also zeroes the top-k workspace the NEXT round will use.
+// The sharded round (sdpcut_shard_finish_round) uses it with d_c4 == NULL (all cap entries exist,
+// those of other shards get ks = 0 / lam = NaN) and a header of world x 64 bytes written elsewhere.
 __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64_t *d_c4, const int64_t *idx,
                                                         const double *score, int64_t idx_base, int64_t n_local,
                                                         const int32_t *set5, const int32_t *ks, const double *vars,
                                                         int32_t nv, int64_t L, int coef_ld, char *block,
-                                                        uint64_t *zero_ptr, int zero_words)
+                                                        int64_t hdr_bytes, uint64_t *zero_ptr, int zero_words)
 {
     __shared__ double tile[64 * SDPCUT_ROW_LD];
     const int lane = threadIdx.x;
     for (int w = blockIdx.x * 64 + lane; w < zero_words; w += gridDim.x * 64) zero_ptr[w] = 0ull;
     int64_t *o_c4 = (int64_t *)block;
-    int64_t *o_idx = (int64_t *)(block + 64);
+    int64_t *o_idx = (int64_t *)(block + hdr_bytes);
     double *o_score = (double *)(o_idx + cap);
     double *o_lam = o_score + cap;
     double *o_rhs = o_lam + cap;
     double *o_coef = o_rhs + cap;
     int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
-    if (blockIdx.x == 0 && lane < 5) o_c4[lane] = d_c4[lane];
-    int64_t limit = d_c4[3];
-    if (limit > cap) limit = cap;
+    int64_t limit = cap;
+    if (d_c4) {
+        if (blockIdx.x == 0 && lane < 5) o_c4[lane] = d_c4[lane];
+        limit = d_c4[3];
+        if (limit > cap) limit = cap;
+    }
     const int64_t first = (int64_t)blockIdx.x * 64;
     const int64_t i = first + lane;
     if (i < limit) {
@@ -1060,7 +1065,7 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
 }
 
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
-                      int coef_ld, void *block)
+                      int coef_ld, void *block, int64_t hdr_bytes)
 {
     if (cap <= 0) return 0;
     uint64_t *zp = nullptr;
@@ -1069,7 +1074,7 @@ int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int
     if (rc) return rc;
     const int grid = (int)((cap + 63) / 64);
     hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
-                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, zp, zw);
+                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw);
     HIP_TRY(h, hipGetLastError());
     h->topk_alt_clean = true;
     return 0;

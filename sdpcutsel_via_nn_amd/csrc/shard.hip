@@ -25,14 +25,21 @@ __global__ void shard_fill_kernel(int64_t count, int64_t *rec)
     }
 }
 
-__global__ void shard_header_kernel(int64_t *rec, const int64_t *c4, int64_t n, int is_opt)
+// header of the record + padding of the slots behind the entries the selection wrote
+__global__ void shard_header_kernel(int64_t *rec, const int64_t *c4, int64_t n, int is_opt, int64_t count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t written = c4[4] ? 0 : c4[3];
+    if (i < count && i >= written) {
+        rec[SHARD_HDR + i] = __double_as_longlong(-__builtin_huge_val());
+        rec[SHARD_HDR + count + i] = 0x7fffffffffffffffLL;
+    }
+    if (i >= 4 && i < SHARD_HDR) rec[i] = (i == 4) ? c4[4] : 0;   // [4] != 0: the selection gave up, record void
+    if (i == 0) {
         rec[0] = is_opt ? n : c4[0];      // length of this shard's list (class size)
         rec[1] = c4[1];                   // nb_violated
         rec[2] = c4[2];                   // nb_positive
         rec[3] = c4[3];                   // entries actually written
-        rec[4] = c4[4];                   // != 0: the selection gave up (topk.hip), the record is void
     }
 }
 
@@ -84,16 +91,49 @@ extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t coun
     if ((h->scored & need) != need) return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
     HIP_TRY(h, hipSetDevice(h->device));
     int64_t *rec = (int64_t *)d_record;
-    hipLaunchKernelGGL(shard_fill_kernel, dim3((int)((count + 255) / 256)), dim3(256), 0, h->stream, count, rec);
+    const int grid = (int)((count + 255) / 256);
     if (h->N > 0) {
         const int64_t *d_c4 = nullptr;
         int rc = rank_fast_enqueue(h, strat, 0, count, rec + SHARD_HDR + count, (double *)(rec + SHARD_HDR), &d_c4);
         if (rc < 0) return rc;
         if (rc != 1) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: request not eligible for the select path");
-        hipLaunchKernelGGL(shard_header_kernel, dim3(1), dim3(64), 0, h->stream, rec, d_c4, h->N,
-                           strat == SDPCUT_STRAT_OPT ? 1 : 0);
+        hipLaunchKernelGGL(shard_header_kernel, dim3(grid), dim3(256), 0, h->stream, rec, d_c4, h->N,
+                           strat == SDPCUT_STRAT_OPT ? 1 : 0, count);
+    } else {
+        hipLaunchKernelGGL(shard_fill_kernel, dim3(grid), dim3(256), 0, h->stream, count, rec);   // empty shard
     }
     HIP_TRY(h, hipGetLastError());
+    return SDPCUT_OK;
+}
+
+extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, int64_t count, const void *d_allrec,
+                                              int64_t sel_size, int32_t coef_ld, const void **block)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || !block)
+        return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish_round arguments");
+    if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD) return sdpcut_fail(h, SDPCUT_EINVAL, "bad coef_ld");
+    if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t tot = (size_t)world * count, s = (size_t)sel_size;
+    // pinned host block, written by the device: headers | ids | scores | lam | rhs | coef | ks
+    const size_t hdr_b = (size_t)world * SHARD_HDR * 8;
+    const size_t ret_bytes = hdr_b + s * 8 * (4 + (size_t)coef_ld) + s * 4;
+    int rc = ensure_stage(h, s * 16 + 64);
+    if (rc) return rc;
+    rc = ensure_pinned(h, ret_bytes);
+    if (rc) return rc;
+    int64_t *d_mi = (int64_t *)h->d_stage;
+    double *d_ms = (double *)(d_mi + s);
+    const size_t nthr = tot > (size_t)world * SHARD_HDR ? tot : (size_t)world * SHARD_HDR;
+    hipLaunchKernelGGL(shard_mergerank_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, h->stream, (int)world,
+                       count, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, (int64_t *)h->pinned_dev);
+    // rows of the merged head that live on this shard (the others are marked ks = 0, lam = NaN),
+    // stored -- with the merged ids and scores -- straight into the host block
+    rc = launch_round_rows(h, sel_size, nullptr, d_mi, d_ms, coef_ld, h->pinned_dev, (int64_t)hdr_b);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *block = h->pinned;
     return SDPCUT_OK;
 }
 
@@ -102,37 +142,13 @@ extern "C" int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t
                                          double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || !headers_out ||
-        !idx_out || !score_out || !lam_min || !coef || !rhs || !ks)
+    if (!headers_out || !idx_out || !score_out || !lam_min || !coef || !rhs || !ks)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish_round arguments");
-    if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD) return sdpcut_fail(h, SDPCUT_EINVAL, "bad coef_ld");
-    if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const size_t tot = (size_t)world * count, s = (size_t)sel_size;
-    // device block, returned by ONE transfer: headers | ids | scores | lam | rhs | coef | ks
-    const size_t hdr_b = (size_t)world * SHARD_HDR * 8;
-    const size_t ret_bytes = hdr_b + s * 8 * (4 + (size_t)coef_ld) + s * 4;
-    int rc = ensure_stage(h, ret_bytes + 64);
+    const void *block = nullptr;
+    int rc = sdpcut_shard_finish_round_view(h, world, count, d_allrec, sel_size, coef_ld, &block);
     if (rc) return rc;
-    rc = ensure_pinned(h, ret_bytes);
-    if (rc) return rc;
-    char *p = (char *)h->d_stage;
-    int64_t *d_hdr = (int64_t *)p; p += hdr_b;
-    int64_t *d_mi = (int64_t *)p; p += s * 8;
-    double *d_ms = (double *)p; p += s * 8;
-    double *d_lam = (double *)p; p += s * 8;
-    double *d_rhs = (double *)p; p += s * 8;
-    double *d_coef = (double *)p; p += s * 8 * (size_t)coef_ld;
-    int32_t *d_ks = (int32_t *)p;
-    const size_t nthr = tot > (size_t)world * SHARD_HDR ? tot : (size_t)world * SHARD_HDR;
-    hipLaunchKernelGGL(shard_mergerank_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, h->stream, (int)world,
-                       count, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, d_hdr);
-    // rows of the merged head that live on this shard (the others are marked ks = 0, lam = NaN)
-    rc = launch_cut_rows(h, sel_size, nullptr, d_mi, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const char *q = (const char *)h->pinned;
+    const size_t s = (size_t)sel_size, hdr_b = (size_t)world * SHARD_HDR * 8;
+    const char *q = (const char *)block;
     std::memcpy(headers_out, q, hdr_b); q += hdr_b;
     std::memcpy(idx_out, q, s * 8); q += s * 8;
     std::memcpy(score_out, q, s * 8); q += s * 8;

@@ -30,6 +30,7 @@ class DeviceOps(object):
 
     def __init__(self, scorer, device):
         self.scorer, self.device = scorer, device
+        self._rec = {}
         # run the library on torch's current stream: its kernels, torch's copies and the
         # collectives torch enqueues are then ordered without host synchronisation
         scorer.set_stream(torch.cuda.current_stream(device).cuda_stream)
@@ -56,7 +57,9 @@ class DeviceOps(object):
 
     def shard_head(self, strat, count):
         """packed head record of this shard, enqueued on the current stream (no host sync)"""
-        rec = torch.empty(8 + 2 * count, dtype=torch.int64, device=self.device)
+        rec = self._rec.get(count)           # one buffer per head length, reused every round
+        if rec is None:
+            rec = self._rec[count] = torch.empty(8 + 2 * count, dtype=torch.int64, device=self.device)
         self.scorer.shard_head_device(strat, count, rec.data_ptr())
         return rec
 
@@ -85,6 +88,7 @@ class ShardedSelector(object):
 
     def __init__(self, ops, n_local, group=None):
         self.ops, self.group = ops, group
+        self._gathered = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_local = int(n_local)
         self.n_global = self._sum(self.n_local)
@@ -104,7 +108,10 @@ class ShardedSelector(object):
         if self.world == 1:
             return t
         if dist.get_backend(self.group) == "nccl":
-            out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+            key = (t.numel(), t.dtype)
+            out = self._gathered.get(key)    # reused: the consumers are stream-ordered behind the collective
+            if out is None:
+                out = self._gathered[key] = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t, group=self.group)
             return out
         host = t.cpu()
@@ -204,7 +211,7 @@ class ShardedSelector(object):
                 cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))
                 if strat == 4:
                     cnt.update(strong=sel, violated=sel)
-                return dict(ids=out["idx"][:valid], scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
+                return dict(ids=out["idx"][:valid].copy(), scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
                             mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
                             rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine], new_strat=strat,
                             n_total=self.n_global if strat != 1 else length, counters=cnt)
