@@ -327,8 +327,63 @@ def golden_triangles(qp):
     np.savez_compressed(os.path.join(HERE, "inst_tri.npz"), **out)
 
 
+def golden_qcqp50(qcqp):
+    """BASELINE.json config 5 at full size: q_50_10_25_1 with 5-variable sub-problems.  The
+    objective cover has 4 of them, the constraints-only cover 1 377 077; one selection round of
+    the reference (cut_select_qcqp.py:63-103) at a random McCormick-feasible point.  Stored: the
+    point, a checksum of the reference's covers (the test re-enumerates them natively) and the
+    first 5000 entries of every strategy's combined list."""
+    import zlib
+    rng = np.random.default_rng(23)
+    name = "q_50_10_25_1"
+    cs = qcqp.CutSolverQCQP()
+    cs._dim = 5
+    cs._CutSolverQCQP__parse_qcqp_osil_into_cplex(name)
+    cs._load_neural_nets()
+    agg_cons = cs._CutSolverQCQP__get_vertex_cover(5)
+    agg_obj = cs._agg_list[:]
+    n = cs._nb_vars
+    vv = harness.random_mccormick_point(n, rng)
+    So, ko = pack_agg(agg_obj)
+    Sc, kc = pack_agg(agg_cons)
+    out = dict(nb_vars=np.int64(n), vars=vv, obj_set_inds=So, obj_k=ko, cons_count=np.int64(len(agg_cons)),
+               cons_crc=np.int64(zlib.crc32(np.ascontiguousarray(Sc).tobytes())), cons_k_all5=np.bool_((kc == 5).all()))
+    print("qcqp50: obj cover", len(agg_obj), "cons-only cover", len(agg_cons), flush=True)
+    cs._agg_list = agg_cons
+    feas = cs._sel_eigcut_by_ordering_on_measure(1, vv, 1)      # 1.4e6 eigvalsh calls
+    out["cons_nb_violated"] = np.int64(len(feas))
+    key_o = {tuple(e[0]): i for i, e in enumerate(agg_obj)}
+    key_c = {tuple(e[0]): i for i, e in enumerate(agg_cons)}
+    sel = 5000
+    for strat in (1, 2, 4):
+        cs._agg_list = agg_obj
+        if strat == 4:
+            new_strat, comb = cs._sel_eigcut_by_ordering_on_measure(4, vv, 1, sel_size=sel)
+        else:
+            new_strat, comb = strat, cs._sel_eigcut_by_ordering_on_measure(strat, vv, 1)
+        rl = (comb + feas)[0:sel]
+        q = "s%d" % strat
+        out[q + "_new_strat"] = np.int64(new_strat)
+        out[q + "_is_obj"] = np.array([isinstance(e[0], int) for e in rl])
+        out[q + "_score"] = np.array([e[1] for e in rl], dtype=np.float64)
+        ids = []
+        for pos, e in enumerate(rl):
+            if isinstance(e[0], int):
+                ids.append(e[0])
+            else:
+                src = key_o if (strat == 1 and pos < len(comb)) else key_c
+                ids.append(src[tuple(e[0])])
+        out[q + "_ids"] = np.array(ids, dtype=np.int64)
+        out[q + "_nb_opt_cuts"] = np.int64(sum(1 for e in comb if e[1] > 1000))
+        print("qcqp50 strat", strat, "comb", len(comb), "head", len(rl), flush=True)
+    np.savez_compressed(os.path.join(HERE, "inst_qcqp50.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if only == "qcqp50":          # minutes of reference Python: not part of "all"
+        golden_qcqp50(import_reference()[1])
+        sys.exit(0)
     if only in ("all", "fig8"):
         golden_fig8()
     if only in ("all", "random"):

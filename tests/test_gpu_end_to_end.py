@@ -93,3 +93,72 @@ def test_qcqp_rounds_q_20_4_25_1(strat):
         assert nb_cuts[1] == sel_size and objs[-1] >= objs[0]
     else:
         assert nb_cuts[1] == 0            # faithful to the reference: 19 unviolated objective entries fill the quota
+
+
+@pytest.mark.parametrize("strat", [4, 2, 1])
+def test_config5_q50_round_matches_reference_at_full_size(strat):
+    """BASELINE.json config 5 on one GPU: q_50_10_25_1, 5-variable sub-problems -- 4 in the
+    objective cover, 1 377 077 in the constraints-only cover (natively enumerated, checksum against
+    the reference's own enumeration).  One selection round of the REFERENCE at a random
+    McCormick-feasible point is the golden (tests/golden/inst_qcqp50.npz, ~5 minutes of the
+    reference's Python per strategy-independent part); the first 5000 entries must be identical."""
+    import zlib
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, harness
+    from sdpcutsel_via_nn_amd.cut_solver import AggArrays
+    g = np.load(os.path.join(GOLDEN, "inst_qcqp50.npz"))
+    inst = harness.parse_osil(os.path.join(GOLDEN, "instances", "q_50_10_25_1.osil"))
+    n = inst["nb_vars"]
+    assert n == int(g["nb_vars"]) == 50
+    (So, ko), (Sc, kc) = harness.qcqp_covers(inst, 5, _capi.enumerate_cover)
+    assert np.array_equal(So[:, :5], g["obj_set_inds"][:, :5]) and np.array_equal(ko, g["obj_k"])
+    assert len(kc) == int(g["cons_count"]) == 1377077 and bool(g["cons_k_all5"]) and (kc == 5).all()
+    assert zlib.crc32(np.ascontiguousarray(Sc[:, :5], dtype=np.int32).tobytes()) == int(g["cons_crc"])
+    L = n * (n + 1) // 2
+    cs = pkg.CutSolverQCQP()
+    cs._sparse_pair = harness.SparsePair
+    lp = harness.LinearRelaxation(np.zeros(L + n))
+    agg_o, agg_c = AggArrays(So, ko, n, inst["Q_arr"]), AggArrays(Sc, kc, n, inst["Q_arr"])
+    cs.set_instance(n, inst["Q_arr"], agg_o, dim=5, my_prob=lp)
+    sel = 5000
+    new_strat, rank_list, nb_cuts, nb_opt = cs.select_and_generate_round(strat, g["vars"], 1, sel, agg_o, agg_c)
+    q = "s%d" % strat
+    assert new_strat == int(g[q + "_new_strat"])
+    head = rank_list[0:sel]
+    is_obj = np.array([isinstance(e[0], int) for e in head])
+    assert np.array_equal(is_obj, g[q + "_is_obj"])
+    score = np.array([e[1] for e in head])
+    assert np.abs(score - g[q + "_score"]).max() <= 1e-9 * max(1.0, np.abs(g[q + "_score"]).max())
+    # identity of the selected sub-problems: objective entries carry their index, feasibility entries
+    # their index set -- map the latter back to positions in the cover they came from
+    key_o = {tuple(int(v) for v in So[i, :ko[i]]): i for i in range(len(ko))}
+    code = lambda S: ((((S[:, 0].astype(np.int64) * 64 + S[:, 1]) * 64 + S[:, 2]) * 64 + S[:, 3]) * 64 + S[:, 4])
+    cons_code = code(Sc)
+    order = np.argsort(cons_code)
+    n_comb = int(is_obj.sum()) if strat != 1 else None
+    ids = []
+    for pos, e in enumerate(head):
+        if isinstance(e[0], int):
+            ids.append(e[0])
+            continue
+        s = tuple(int(v) for v in e[0])
+        from_obj = strat == 1 and s in key_o and pos < len(key_o)
+        if from_obj:
+            ids.append(key_o[s])
+        else:
+            c = code(np.array([s], dtype=np.int64))[0]
+            ids.append(int(order[np.searchsorted(cons_code[order], c)]))
+    ids = np.array(ids, dtype=np.int64)
+    ref_ids = g[q + "_ids"]
+    same = ids == ref_ids
+    if not same.all():
+        # the only admissible difference: neighbours whose reference scores agree to 1e-12 (LAPACK noise)
+        bad = np.flatnonzero(~same)
+        ref_score = g[q + "_score"]
+        for b in bad:
+            lo, hi = max(b - 3, 0), min(b + 4, len(ids))
+            assert np.ptp(ref_score[lo:hi][np.isin(ref_ids[lo:hi], ids[lo:hi])]) <= 1e-12 * max(1.0, abs(ref_score[b])), b
+        assert len(bad) <= 10
+    if strat != 1:
+        assert nb_opt == int(g[q + "_nb_opt_cuts"])
+    assert nb_cuts == lp.linear_constraints.get_num() > 0
