@@ -646,3 +646,53 @@ def test_select_round_general_regime(full_c2, scorer):
     v = scorer.select_round(2, 100, copy=False)           # fast path again right after the fallback
     ids2, score2, _, _, _ = scorer.rank(2, 100, max_out=100)
     assert np.array_equal(v["idx"], ids2) and np.array_equal(v["score"], score2)
+
+
+# --------------------------------------------------------------------------- config 4: one shard at full size
+def test_config4_shard_full_size_properties(lib, oracle):
+    """BASELINE.json config 4, the share of one of 8 GPUs: n = 1000 (500 500 lifted variables, a
+    4 MB LP point), 1.25e7 three-variable candidates with global_base of rank 5.  Size-independent
+    properties: sampled scores equal the oracle's, equal index sets score bit-identically, the
+    head of every strategy is the oracle's ranking of the device's own scores (global ids), and
+    the fused round returns the rows of that head."""
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    n, N, base = 1000, 12_500_000, 5 * 12_500_000
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=N, seed=12)
+    sc = lib.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"], global_base=base)
+        sc.set_point(wl["vars_values"])
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.isfinite(eig).all() and np.isfinite(obj).all()
+        rng = np.random.default_rng(5)
+        pick = np.concatenate([np.arange(2048), N - 1 - np.arange(2048), rng.choice(N, 8192, replace=False)])
+        si = wl["set_inds"][pick, :3]
+        vv, L = wl["vars_values"], n * (n + 1) // 2
+        ref_obj = oracle.opt_score_batch(3, si, n, vv, wl["Q_arr"])
+        ref_eig = oracle.eigmin_batch(3, vv[L:][si], vv[:L][oracle.triu_positions(si, n)])
+        assert np.abs(eig[pick] - ref_eig).max() <= EIG_ATOL
+        assert obj_close(obj[pick], ref_obj, max_elem_of(oracle, wl["set_inds"][pick], 3, n, wl["Q_arr"]))
+        s = wl["set_inds"][:, :3].astype(np.int64)
+        code = (s[:, 0] * 1000 + s[:, 1]) * 1000 + s[:, 2]
+        order = np.argsort(code, kind="stable")
+        same = code[order][1:] == code[order][:-1]
+        assert same.sum() > 100000            # 1.25e7 draws from 1.66e8 triples: ~4.6e5 repeated draws
+        assert np.array_equal(eig[order][1:][same], eig[order][:-1][same])
+        assert np.array_equal(obj[order][1:][same], obj[order][:-1][same])
+        for strat in (1, 2, 4):
+            ids, score, total, new_strat, cnt = sc.rank(strat, 5000, max_out=5000)
+            ref_order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, 5000)
+            assert np.array_equal(ids, ref_order[:5000] + base), strat
+            assert np.array_equal(score, ref_score[:5000] + 0.0) and new_strat == ref_strat
+            assert total == ref_order.shape[0]
+        r = sc.select_round(4, 5000)
+        ref_order, ref_score, _, _ = oracle.rank_arrays(4, obj, eig, 5000)
+        assert np.array_equal(r["idx"], ref_order[:5000] + base) and np.array_equal(r["score"], ref_score[:5000] + 0.0)
+        lam, coef, rhs, cols, ks = sc.cut_rows(ref_order[:5000])
+        assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :9]) and np.array_equal(r["rhs"], rhs)
+        assert (lam < -1e-15).all() and np.abs(lam - eig[ref_order[:5000]]).max() <= 1e-15
+    finally:
+        sc.close()
