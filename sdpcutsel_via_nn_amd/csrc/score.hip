@@ -406,7 +406,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 // alone hipcc loads each fragment right before its two MFMAs and waits vmcnt(0)
                 // (an L2 round trip per 128 MFMA cycles, the dominant stall in the first PMC run):
                 // a ring of RD fragments keeps RD-1 loads in flight; the sched_barriers pin the order.
-                constexpr int RD = 4, NG = TM * SH;
+#ifndef SDPCUT_RING_DEPTH
+#define SDPCUT_RING_DEPTH 4
+#endif
+                constexpr int RD = SDPCUT_RING_DEPTH, NG = TM * SH;
                 double ring[RD];
 #pragma unroll
                 for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = WFRAG_AT(g * 64 + lane);

@@ -10,7 +10,9 @@ python -m $P.build >/dev/null 2>&1
 for spec in "$@"; do
   name=${spec%%:*}
   flags=""
-  if [[ "$spec" == *:* ]]; then for f in $(echo ${spec#*:} | tr , ' '); do flags="$flags -DSDPCUT_ABL_$f"; done; fi
+  # FLAG -> -DSDPCUT_ABL_FLAG ; NAME=VALUE -> -DSDPCUT_NAME=VALUE (e.g. RING_DEPTH=6)
+  if [[ "$spec" == *:* ]]; then for f in $(echo ${spec#*:} | tr , ' '); do
+    if [[ "$f" == *=* ]]; then flags="$flags -DSDPCUT_$f"; else flags="$flags -DSDPCUT_ABL_$f"; fi; done; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $P/csrc/score.hip -o $P/_abl/score_$name.o &
 done
 wait
