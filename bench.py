@@ -26,7 +26,8 @@ N_PER_GPU = 10 ** 6
 NB_VARS = 100
 K = 3
 SEL = 5000
-PREWARM_STEPS = 150     # untimed setup before the W warmup steps (GPU clock ramp), see main()
+BASELINE_METRIC = "candidate cuts scored/sec (eig+NN), 1e6 3-var subs, 1/2/4/8 GPU"    # BASELINE.json "metric"
+PREWARM_STEPS = 150    # untimed setup before the W warmup steps (GPU clock ramp), see main()
 FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only, BASELINE.md section 4
 BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
@@ -173,7 +174,7 @@ def main():
         if os.path.exists(tfile):      # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes)
             traffic = json.load(open(tfile)).get(args.kernel)
         out = {
-            "metric": "candidate cuts scored/sec (eig+NN)", "value": total / dt, "unit": "candidates/s",
+            "metric": BASELINE_METRIC, "value": total / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, "
