@@ -122,33 +122,45 @@ __device__ __forceinline__ double tansig_lib(double n)
     return 2.0 / (exp(-2.0 * n) + 1.0) - 1.0;
 }
 
-// The same formula with a branch-free exp and reciprocal: 25 VALU instructions instead of the
+// The same formula with a branch-free exp and reciprocal: 23 VALU instructions instead of the
 // ~36 of the library route (every VALU instruction costs ~2-2.5 ns per wave on gfx950 whatever
 // its type, v_rcp_f64 ~7 ns: profiles/r01_ubench_fp64_instruction_costs.txt -- the COUNT is
-// what matters).  With y = -2n:  exp(y) = 2^k * exp(r/8)^8,  k = rint(y log2 e),  r/8 = y/8 -
-// k ln2/8 in two pieces (|r/8| <= 0.0433), degree-8 Taylor polynomial (truncation 2e-18), three
-// squarings; only the upper clamp is needed (y <= 704 keeps exp finite; towards -inf ldexp
-// underflows to 0 and the result saturates at +1 by itself).  The reciprocal is v_rcp_f64
-// (4.5e-8) + one cubically convergent step.  Absolute error vs the exact formula <= 1e-15.
+// what matters).
+//
+// exp(-2n): with y = -2n,  exp(y) = 2^k * exp(r/8)^8,  k = rint(y log2 e),  r/8 = y/8 - k ln2/8
+// (|r/8| <= ln2/16 = 0.0433), three squarings.
+//  * one-constant reduction: fl(ln2/8) is off by <= 7e-18, so r/8 is off by <= |k| 7e-18; where
+//    tansig is sensitive to exp (|k| <= 40, sensitivity 2e/(1+e)^2 <= 1/2) that is <= 3e-16 in
+//    the result, in saturation the sensitivity kills it;
+//  * degree-7 near-minimax polynomial (truncated Chebyshev series of exp on |r| <= ln2/16;
+//    coefficients computed in 60-digit arithmetic): max relative error 5e-18, the accuracy of the
+//    degree-8 Taylor polynomial with one FMA less;
+//  * only the upper clamp is needed (y8max = 88 keeps exp finite; towards -inf ldexp underflows
+//    to 0 and tansig saturates at +1 by itself).
+__device__ __forceinline__ double exp_m2n(double n, double y8max)
+{
+    const double y8 = fmin(n * -0.25, y8max);
+    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
+    const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)
+    double p = 0x1.a02041015378fp-13;
+    p = fma(p, r, 0x1.6c1d00cea5bf1p-10);
+    p = fma(p, r, 0x1.111111080fc42p-7);
+    p = fma(p, r, 0x1.5555554653263p-5);
+    p = fma(p, r, 0x1.5555555555689p-3);
+    p = fma(p, r, 0x1.0000000000171p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    return ldexp(p, (int)k);
+}
+
+// The reciprocal is v_rcp_f64 (4.5e-8) + one cubically convergent step.  Absolute error of
+// tansig vs the exact formula <= 1e-15.
 __device__ __forceinline__ double tansig(double n)
 {
-    const double y8 = fmin(n * -0.25, 88.0);
-    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
-    double r = fma(k, -8.66433975461404770613e-02, y8);              // ln2_hi / 8
-    r = fma(k, -2.38526866158823462503e-11, r);                      // ln2_lo / 8
-    double p = 2.48015873015873015873e-05;              // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);          // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);          // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);          // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);          // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);          // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    const double d = ldexp(p, (int)k) + 1.0;
+    const double d = exp_m2n(n, 88.0) + 1.0;
     double q = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, q, 1.0);
     q = fma(q, fma(e, e, e), q);                        // q (1 + e + e^2)
@@ -159,23 +171,7 @@ __device__ __forceinline__ double tansig(double n)
 // the product of four denominators stays finite (tansig(-88) is -1 to 2e-76 either way).
 __device__ __forceinline__ double tansig_den(double n)
 {
-    const double y8 = fmin(n * -0.25, 22.0);
-    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
-    double r = fma(k, -8.66433975461404770613e-02, y8);              // ln2_hi / 8
-    r = fma(k, -2.38526866158823462503e-11, r);                      // ln2_lo / 8
-    double p = 2.48015873015873015873e-05;              // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);          // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);          // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);          // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);          // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);          // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    return ldexp(p, (int)k) + 1.0;
+    return exp_m2n(n, 22.0) + 1.0;
 }
 
 // Four tansig values with ONE reciprocal: 1/d_i = (1 / (d0 d1 d2 d3)) * prod_{j != i} d_j.
