@@ -60,14 +60,17 @@ struct Cand {
 };
 
 template <int K>
-__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set, int64_t n, int64_t c,
-                                                 const double *vars, const double *Q, int32_t nv,
-                                                 int64_t L, bool want_q)
+__device__ __forceinline__ void load_index_set(int32_t (&s)[K], const int32_t *set, int64_t n, int64_t c)
 {
-    constexpr int M = K * (K + 1) / 2;
-    int32_t s[K];
 #pragma unroll
     for (int a = 0; a < K; ++a) s[a] = set[(int64_t)a * n + c];
+}
+
+template <int K>
+__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t (&s)[K], const double *vars,
+                                                 const double *Q, int32_t nv, int64_t L, bool want_q)
+{
+    constexpr int M = K * (K + 1) / 2;
 #pragma unroll
     for (int a = 0; a < K; ++a) cd.x[a] = vars[L + s[a]];
     int32_t pos[M];
@@ -105,6 +108,16 @@ __device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set
             cd.negSM = (-S) * me;
         }
     }
+}
+
+template <int K>
+__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set, int64_t n, int64_t c,
+                                                 const double *vars, const double *Q, int32_t nv,
+                                                 int64_t L, bool want_q)
+{
+    int32_t s[K];
+    load_index_set<K>(s, set, n, c);
+    gather_candidate<K>(cd, s, vars, Q, nv, L, want_q);
 }
 
 template <int K>
@@ -305,13 +318,36 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         __syncthreads();
     }
 
+    // The index set (and the output slot) of the NEXT tile are requested before phase B of the
+    // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
+    // L2: the gathers they address) is off the critical path.
+    int32_t s_nxt[K];
+    int32_t orig_nxt = 0;
+    if ((int64_t)blockIdx.x < ntiles) {
+        const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t cc0 = c0 < A.n ? c0 : A.n - 1;
+        load_index_set<K>(s_nxt, A.set, A.n, cc0);
+        orig_nxt = A.orig[cc0];
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t c = tile * 256 + threadIdx.x;
         const bool valid = c < A.n;
-        const int64_t cc = valid ? c : A.n - 1;
+        int32_t s_cur[K];
+#pragma unroll
+        for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
+        const int32_t out_idx = orig_nxt;
         Cand<K> cd;
-        gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
-        const int32_t out_idx = A.orig[cc];
+        gather_candidate<K>(cd, s_cur, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
+        {
+            const int64_t tn = tile + gridDim.x;
+            if (tn < ntiles) {               // uniform
+                const int64_t c1 = tn * 256 + threadIdx.x;
+                const int64_t cc1 = c1 < A.n ? c1 : A.n - 1;
+                load_index_set<K>(s_nxt, A.set, A.n, cc1);
+                orig_nxt = A.orig[cc1];
+            }
+        }
 
         double lam = 0.0;
         if (A.flags & SDPCUT_EIG) {
@@ -943,6 +979,11 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double *Am, const 
 
 // ------------------------------------------------------------------------------------------
 // host launchers
+// workgroups per CU launched for the MFMA kernel (2 are resident at a time: 2 waves / SIMD)
+#ifndef SDPCUT_MFMA_BLOCKS_PER_CU
+#define SDPCUT_MFMA_BLOCKS_PER_CU 8
+#endif
+
 static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
 {
     int64_t cap = (int64_t)h->n_cu * per_cu;
@@ -999,7 +1040,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         if (K == 5) SCORE_LAUNCH((score_valu_kernel<5, 64, 4>), grid, 256);
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
-        const int grid = grid_for(h, ntiles, 8);
+        const int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
         if (A.tk) {
             if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true>), grid, 256);
             if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
@@ -1031,7 +1072,7 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
         for (int k = 2; k <= SDPCUT_MAX_K && ok; ++k) {
             if (h->bucket[k].n == 0) continue;
             ok = net_shape_ok(h, k, flags);
-            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, 8);
+            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
         }
         if (!ok || fuse_blocks == 0) fuse = nullptr;
         else if (fused) *fused = true;
