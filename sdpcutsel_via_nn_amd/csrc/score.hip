@@ -279,6 +279,30 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #define WFRAG_AT(i) wf[i]
 #endif
 
+// Timing experiment (tools/build_ablation.sh ...:PHASETIME): cycles a wave spends between the phase
+// boundaries of a tile, printed by a few waves.  [0-1] gather wait, [1-2] Jacobi, [2-3] staging,
+// [3-4] the MLP passes.
+#ifdef SDPCUT_ABL_PHASETIME
+#define PHASE_DECL unsigned long long ph_t[5] = {0, 0, 0, 0, 0}, ph_acc[4] = {0, 0, 0, 0}; int ph_n = 0
+#define PHASE_MARK(i)                                                      \
+    do {                                                                   \
+        ph_t[i] = __builtin_readcyclecounter();                            \
+        if ((i) > 0) ph_acc[(i) - 1] += ph_t[i] - ph_t[(i) - 1];           \
+        if ((i) == 4) ++ph_n;                                              \
+    } while (0)
+#define PHASE_WAITMEM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PHASE_REPORT                                                                                        \
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x % 509) == 3)                                                 \
+    printf("blk %d wave %d tiles %d: gather %llu jacobi %llu stage %llu mlp %llu cycles/tile\n", (int)blockIdx.x, \
+           (int)(threadIdx.x >> 6), ph_n, ph_acc[0] / (ph_n ? ph_n : 1), ph_acc[1] / (ph_n ? ph_n : 1),      \
+           ph_acc[2] / (ph_n ? ph_n : 1), ph_acc[3] / (ph_n ? ph_n : 1))
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_WAITMEM
+#define PHASE_REPORT
+#endif
+
 // ------------------------------------------------------------------------------------------
 // MFMA kernel.  K candidate size, H hidden width, NH hidden layers; FUSE: also run the first pass
 // of the top-k selection (ScoreArgs::tk).
@@ -330,7 +354,9 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         orig_nxt = A.orig[cc0];
     }
 
+    PHASE_DECL;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        PHASE_MARK(0);
         const int64_t c = tile * 256 + threadIdx.x;
         const bool valid = c < A.n;
         int32_t s_cur[K];
@@ -350,10 +376,13 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         }
 
         double lam = 0.0;
+        PHASE_WAITMEM;
+        PHASE_MARK(1);
         if (A.flags & SDPCUT_EIG) {
             lam = candidate_eigmin<K>(cd);
             if (valid) A.eig_out[out_idx] = lam;
         }
+        PHASE_MARK(2);
         if (!(A.flags & SDPCUT_NN)) {           // uniform branch
             if constexpr (FUSE) {
                 uint64_t key = 0;
@@ -379,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             feat[wave][i][lane] = xp;
         }
         wave_lds_sync();
+        PHASE_MARK(3);
 
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
@@ -524,7 +554,9 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
+        PHASE_MARK(4);
     }
+    PHASE_REPORT;
     if constexpr (FUSE) {   // same tail as tk_keys_kernel: class counters, then the pass hand-off
         if (c_class) atomicAdd(&tk_cnt[0], c_class);
         if (c_viol) atomicAdd(&tk_cnt[1], c_viol);
