@@ -1,0 +1,114 @@
+"""Randomised differential test through the C-ABI: small random instances with mixed candidate
+sizes, odd list lengths (1, 63..65, 255..257, ...), random strategies, head lengths and kernel
+options, against the oracle.  Catches the corner cases the structured tests do not enumerate."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EIG_ATOL = 2e-13
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import sdpcutsel_via_nn_amd as pkg
+    return pkg
+
+
+def _instance(rng, n, N, kinds):
+    from sdpcutsel_via_nn_amd import synthetic
+    L = n * (n + 1) // 2
+    Q = np.round(rng.normal(size=L) * 20) * (rng.uniform(size=L) < rng.choice([0.3, 0.7, 1.0]))
+    ks = rng.choice(kinds, size=N).astype(np.int32)
+    sets = np.full((N, 5), -1, dtype=np.int32)
+    for k in np.unique(ks):
+        m = ks == k
+        sets[m, :k] = synthetic.random_index_sets(n, int(k), int(m.sum()), rng)
+    return Q, sets, ks
+
+
+def _point(rng, n, kind):
+    iu = np.triu_indices(n)
+    x = rng.uniform(0, 1, n)
+    if kind == "psd":                       # X = min(x_i, x_j): lifted matrix PSD, nothing violated
+        X = np.minimum(x[iu[0]], x[iu[1]])
+    elif kind == "mid":                     # structured vertex: many exactly equal scores
+        x = np.full(n, 0.5)
+        X = rng.choice([0.0, 0.5], size=iu[0].shape[0])
+    else:                                   # generic McCormick-feasible point
+        lo = np.maximum(0.0, x[iu[0]] + x[iu[1]] - 1.0)
+        hi = np.minimum(x[iu[0]], x[iu[1]])
+        X = lo + rng.uniform(size=lo.shape[0]) * (hi - lo)
+    return np.concatenate([X, x])
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_instances_against_the_oracle(lib, oracle, seed):
+    from sdpcutsel_via_nn_amd import _capi, networks
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(6, 41))
+    N = int(rng.choice([1, 2, 5, 63, 64, 65, 255, 256, 257, 1000, 4097, 9001]))
+    kinds = [k for k in (2, 3, 4, 5) if k <= n and rng.uniform() < 0.6] or [3]
+    Q, sets, ks = _instance(rng, n, N, kinds)
+    vv = _point(rng, n, rng.choice(["gen", "gen", "mid", "psd"]))
+    L = n * (n + 1) // 2
+    sc = lib.Scorer(0)
+    try:
+        for k in range(2, 6):
+            sc.set_network(k, *networks.load_network(k))
+        sc.set_instance(n, Q)
+        base = int(rng.choice([0, 0, 7, 10 ** 9]))
+        sc.set_candidates(sets, ks, global_base=base)
+        sc.set_option(_capi.OPT_KERNEL, int(rng.choice([_capi.KERNEL_MFMA, _capi.KERNEL_MFMA, _capi.KERNEL_VALU])))
+        sc.set_option(_capi.OPT_FUSE_KEYS, int(rng.integers(0, 2)))
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        # scores against the oracle, per candidate size
+        for k in np.unique(ks):
+            m = np.flatnonzero(ks == k)
+            si = sets[m, :k]
+            ref_obj = oracle.opt_score_batch(int(k), si, n, vv, Q)
+            ref_eig = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][oracle.triu_positions(si, n)])
+            assert np.abs(eig[m] - ref_eig).max() <= EIG_ATOL, (seed, k)
+            tol = 1e-9 * np.maximum(np.abs(ref_obj), 1e-3 * np.abs(ref_obj).max() + 1e-12) + 1e-9
+            assert np.all(np.abs(obj[m] - ref_obj) <= tol), (seed, k)
+        # rankings: exact given the device's scores
+        for _ in range(6):
+            strat = int(rng.choice([1, 2, 4]))
+            sel = int(rng.choice([0, 1, 2, max(N // 10, 1), N, N + 3, 5000]))
+            max_out = int(rng.choice([sel, N, 1, 8192, 10 ** 6]))
+            if strat == 4 and sel == 0:
+                continue
+            ids, score, total, new_strat, cnt = sc.rank(strat, sel, max_out=max_out)
+            order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, sel)
+            w = min(max_out, order.shape[0])
+            assert total == order.shape[0] and new_strat == ref_strat, (seed, strat, sel, max_out)
+            assert np.array_equal(ids, order[:w] + base), (seed, strat, sel, max_out)
+            assert np.array_equal(score, ref_score[:w] + 0.0), (seed, strat, sel, max_out)
+            # the fused round returns the same head and the rows sdpcut_cut_rows gives
+            sc.set_point(vv)                               # clears the scored flags (fusion option)
+            r = sc.select_round(strat, sel)
+            w = min(sel, order.shape[0], N)
+            assert np.array_equal(r["idx"], order[:w] + base), (seed, strat, sel)
+            assert np.array_equal(r["score"], ref_score[:w] + 0.0)
+            assert r["n_total"] == order.shape[0] and r["new_strat"] == ref_strat
+            if w:
+                lam, coef, rhs, cols, kk = sc.cut_rows(order[:w])
+                ld = r["coef"].shape[1]
+                assert np.array_equal(r["lam"], lam) and np.array_equal(r["rhs"], rhs) and np.array_equal(r["ks"], kk)
+                assert np.array_equal(r["coef"], coef[:, :ld]) and not coef[:, ld:].any()
+                assert np.abs(lam - eig[order[:w]]).max() <= 1e-14
+                # the row is v^T [[1, x^T], [x, X]] v written out for the unit eigenvector v of lam:
+                # -rhs + coef . (x_rho, X_rho) = lam, and the columns are those of the index set
+                for j in rng.choice(w, size=min(w, 8), replace=False):
+                    c = int(order[j])
+                    k = int(ks[c])
+                    si = sets[c:c + 1, :k]
+                    pos = oracle.triu_positions(si, n)[0]
+                    assert cols[j, :k].tolist() == (L + si[0]).tolist() and cols[j, k:k + len(pos)].tolist() == pos.tolist()
+                    val = -rhs[j] + coef[j, :k] @ vv[L:][si[0]] + coef[j, k:k + len(pos)] @ vv[:L][pos]
+                    assert abs(val - lam[j]) <= 1e-12, (seed, c, val, lam[j])
+            sc.score(_capi.EIG | _capi.NN)
+    finally:
+        sc.close()
