@@ -268,10 +268,29 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 
 // Timing experiments (tools/build_ablation.sh; results are wrong by design): drop the bias or
 // weight-fragment loads to see what their latency costs.
+// Biases, tail-row weights and output weights (<= 8.5 KB) are copied to LDS once per workgroup:
+// they are read at every tile / layer boundary, exactly where a wave has nothing else in flight
+// to cover an L2 round trip (ds_read ~100 cycles instead of ~700).
+#ifndef SDPCUT_SMALL_IN_LDS
+#define SDPCUT_SMALL_IN_LDS 1
+#endif
+// (The A-fragments themselves were tried in LDS too -- 44.5 KB for the 3-variable net, two
+// workgroups per CU still fit: no gain, the register ring already hides their L2 latency.)
 #ifdef SDPCUT_ABL_NOBIAS
 #define BIAS_AT(i) (0.125 + 0.0 * (double)(i))
+#elif SDPCUT_SMALL_IN_LDS
+#define BIAS_AT(i) s_bias[i]
 #else
 #define BIAS_AT(i) net.bias[i]
+#endif
+#if SDPCUT_SMALL_IN_LDS
+#define WTAIL_AT(i) s_wtail[i]
+#define WOUT_AT(i) s_wout[i]
+#define BIAS_PTR s_bias
+#else
+#define WTAIL_AT(i) net.wtail[i]
+#define WOUT_AT(i) net.wout[i]
+#define BIAS_PTR net.bias
 #endif
 #ifdef SDPCUT_ABL_NOWLOAD
 #define WFRAG_AT(i) (0.01 * (double)((i) & 7))
@@ -331,6 +350,19 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     const int c16 = lane & 15;    // MFMA column (candidate within a 16-tile)
     const NetDev &net = A.net;
     const int64_t ntiles = (A.n + 255) / 256;
+
+#if SDPCUT_SMALL_IN_LDS
+    __shared__ double s_bias[NH * 64];
+    __shared__ double s_wtail[NT ? NH * 4 * 64 : 1];
+    __shared__ double s_wout[64];
+    if (A.flags & SDPCUT_NN) {     // uniform; an eigenvalue-only launch may come without a network
+        for (int i = threadIdx.x; i < NH * 64; i += 256) s_bias[i] = net.bias[i];
+        if constexpr (NT > 0)
+            for (int i = threadIdx.x; i < NH * 4 * 64; i += 256) s_wtail[i] = net.wtail[i];
+        if (threadIdx.x < 64) s_wout[threadIdx.x] = net.wout[threadIdx.x];
+        __syncthreads();
+    }
+#endif
 
     // fused first pass of the top-k selection (A.tk != nullptr)
     __shared__ uint32_t tk_hist[256];
@@ -450,11 +482,11 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 for (int s = 0; s < S0; ++s)
 #pragma unroll
                     for (int u = 0; u < NT; ++u) {
-                        const double w = net.wtail[u * 64 + 4 * s + q];
+                        const double w = WTAIL_AT(u * 64 + 4 * s + q);
 #pragma unroll
                         for (int j = 0; j < J; ++j) ts[j][u] = fma(bin[s][j], w, ts[j][u]);
                     }
-                tail_rows2<NT>(ts, net.bias + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                tail_rows2<NT>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
             }
             wf += T * S0 * 64;
             // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
@@ -507,11 +539,11 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                     for (int s = 0; s < SH; ++s)
 #pragma unroll
                         for (int u = 0; u < NT; ++u) {
-                            const double w = net.wtail[(l * 4 + u) * 64 + 4 * s + q];
+                            const double w = WTAIL_AT((l * 4 + u) * 64 + 4 * s + q);
 #pragma unroll
                             for (int j = 0; j < J; ++j) ts[j][u] = fma(prev[s / 4][j][s % 4], w, ts[j][u]);
                         }
-                    tail_rows2<NT>(ts, net.bias + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                    tail_rows2<NT>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
                 }
                 wf += T * SH * 64;
             }
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 for (int t = 0; t < T; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (16 * t + 4 * r < H) part = fma(cur[t][j][r], net.wout[16 * t + 4 * r + q], part);
+                        if (16 * t + 4 * r < H) part = fma(cur[t][j][r], WOUT_AT(16 * t + 4 * r + q), part);
                 part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
                 if (q == 0) ynn[wave][32 * pass + 16 * j + c16] = part;
