@@ -304,6 +304,23 @@ def test_edge_cases_and_errors(lib, scorer, golden_boxqp):
     sc2.score(_capi.EIG)
     ids, _, total, _, _ = sc2.rank(1, 5)
     assert total == 0 and ids.size == 0
+    # eigenvalue-only scoring never needs a network: a handle WITHOUT any sdpcut_set_network call
+    # (every kernel variant, including the MFMA kernel's LDS preload of network constants)
+    sc2.set_candidates(g[tag + "_set_inds"], g[tag + "_k"])
+    sc2.set_point(g[tag + "_rnd_vars"])
+    scorer.set_instance(n, g[tag + "_Q_arr"])
+    scorer.set_candidates(g[tag + "_set_inds"], g[tag + "_k"])
+    scorer.set_point(g[tag + "_rnd_vars"])
+    scorer.score(_capi.EIG)
+    ref_eig = scorer.get_scores(obj=False)[0]
+    for variant in (_capi.KERNEL_MFMA, _capi.KERNEL_VALU, _capi.KERNEL_SIMPLE):
+        sc2.set_option(_capi.OPT_KERNEL, variant)
+        sc2.score(_capi.EIG)
+        assert np.array_equal(sc2.get_scores(obj=False)[0], ref_eig)
+        r = sc2.select_round(1, 10)
+        assert r["idx"].size == min(10, int((ref_eig < -1e-15).sum()))
+    with pytest.raises(lib.SdpCutError):
+        sc2.score(_capi.NN)                                             # ... but the optimality measure does
     sc2.close()
 
 
