@@ -351,6 +351,20 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     const NetDev &net = A.net;
     const int64_t ntiles = (A.n + 255) / 256;
 
+    // The index set (and the output slot) of the NEXT tile are requested before phase B of the
+    // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
+    // L2: the gathers they address) is off the critical path.
+    // (The first tile's request goes out before the LDS preload below so that the two latencies of a
+    // workgroup's start overlap.)
+    int32_t s_nxt[K];
+    int32_t orig_nxt = 0;
+    if ((int64_t)blockIdx.x < ntiles) {
+        const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const int64_t cc0 = c0 < A.n ? c0 : A.n - 1;
+        load_index_set<K>(s_nxt, A.set, A.n, cc0);
+        orig_nxt = A.orig[cc0];
+    }
+
 #if SDPCUT_SMALL_IN_LDS
     __shared__ double s_bias[NH * 64];
     __shared__ double s_wtail[NT ? NH * 4 * 64 : 1];
@@ -372,18 +386,6 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 3) tk_cnt[threadIdx.x] = 0;
         __syncthreads();
-    }
-
-    // The index set (and the output slot) of the NEXT tile are requested before phase B of the
-    // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
-    // L2: the gathers they address) is off the critical path.
-    int32_t s_nxt[K];
-    int32_t orig_nxt = 0;
-    if ((int64_t)blockIdx.x < ntiles) {
-        const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const int64_t cc0 = c0 < A.n ? c0 : A.n - 1;
-        load_index_set<K>(s_nxt, A.set, A.n, cc0);
-        orig_nxt = A.orig[cc0];
     }
 
     PHASE_DECL;
