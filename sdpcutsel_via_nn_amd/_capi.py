@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsdpcut_hip.so")
+LIB_PATH = os.environ.get("SDPCUT_LIB") or os.path.join(HERE, "libsdpcut_hip.so")   # env: experiment builds
 
 EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
