@@ -198,6 +198,9 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
     const size_t o_bias = reserve((size_t)nh * 64);
     for (int l = 0; l < nh; ++l)
         for (int j = 0; j < H; ++j) blob[o_bias + l * 64 + j] = B[l][j];
+    const size_t o_bias_q = reserve((size_t)nh * 64);
+    for (int l = 0; l < nh; ++l)
+        for (int j = 0; j < H; ++j) blob[o_bias_q + l * 64 + j] = -0.25 * B[l][j];
     const size_t o_wout = reserve(64);
     for (int j = 0; j < H; ++j) blob[o_wout + j] = W[nh][j];
     size_t o_rw[MAX_LAYERS], o_rb[MAX_LAYERS];
@@ -223,7 +226,8 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
                 for (int s = 0; s < S; ++s)
                     for (int ln = 0; ln < 64; ++ln) {
                         const int row = 16 * t + (ln & 15), col = 4 * s + (ln >> 4);
-                        blob[o++] = (row < H && col < fan) ? W[l][(size_t)row * fan + col] : 0.0;
+                        // pre-scaled by -1/4 (exact: a power of two), see NetDev::bias_q
+                        blob[o++] = (row < H && col < fan) ? -0.25 * W[l][(size_t)row * fan + col] : 0.0;
                     }
             fan = H;
         }
@@ -235,7 +239,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
         for (int l = 0; l < nh; ++l) {
             for (int u = 0; u < 4; ++u)
                 for (int i = 0; i < fan; ++i)
-                    if (48 + u < H) blob[o_wtail + ((size_t)l * 4 + u) * 64 + i] = W[l][(size_t)(48 + u) * fan + i];
+                    if (48 + u < H) blob[o_wtail + ((size_t)l * 4 + u) * 64 + i] = -0.25 * W[l][(size_t)(48 + u) * fan + i];
             fan = H;
         }
     }
@@ -268,6 +272,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
     d.d_in = d_in; d.n_hidden = nh; d.width = H; d.s0 = s0; d.sh = sh;
     d.inmap = nh_.d_blob + o_inmap;
     d.bias = nh_.d_blob + o_bias;
+    d.bias_q = nh_.d_blob + o_bias_q;
     d.wout = nh_.d_blob + o_wout;
     d.wfrag = nh_.d_blob + o_frag;
     d.wvalu = nh_.d_blob + o_wvalu;

@@ -19,8 +19,13 @@ struct NetDev {
     int n_hidden;          // hidden (tansig) layers
     int width;             // hidden width (all hidden layers equal: 64 or 50)
     int s0, sh;            // k-steps (of 4) of the first / the other hidden layers
-    const double *wfrag;   // MFMA A-fragments: layer-major, then [t][s][lane]
-    const double *wtail;   // [layer][4][64]: rows 48..51 of each hidden layer (VALU tail of the MFMA kernel)
+    // The MFMA kernel's copies of the hidden-layer weights and biases are pre-scaled by -1/4: the
+    // accumulators then hold y/8 = -n/4 of tansig's exp(-2n) = exp(y) directly (exact: scaling by
+    // a power of two commutes with every rounding of the dot product), one multiply less per
+    // activation.
+    const double *wfrag;   // MFMA A-fragments (x -1/4): layer-major, then [t][s][lane]
+    const double *wtail;   // (x -1/4) [layer][4][64]: rows 48..51 of each hidden layer (VALU tail of the MFMA kernel)
+    const double *bias_q;  // (x -1/4) [n_hidden][64] zero padded
     const double *wvalu;   // scalar-operand packing: layer-major, then [j/8][i][j%8], zero padded
     const double *bias;    // [n_hidden][64] zero padded
     const double *wout;    // [64] zero padded output weights

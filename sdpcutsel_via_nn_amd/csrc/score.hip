@@ -150,9 +150,9 @@ __device__ __forceinline__ double tansig_lib(double n)
 //    degree-8 Taylor polynomial with one FMA less;
 //  * only the upper clamp is needed (y8max = 88 keeps exp finite; towards -inf ldexp underflows
 //    to 0 and tansig saturates at +1 by itself).
-__device__ __forceinline__ double exp_m2n(double n, double y8max)
+__device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(8 y8_in), y8_in = -n / 4
 {
-    const double y8 = fmin(n * -0.25, y8max);
+    const double y8 = fmin(y8_in, y8max);
     const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
     const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)
     double p = 0x1.a02041015378fp-13;
@@ -168,6 +168,7 @@ __device__ __forceinline__ double exp_m2n(double n, double y8max)
     p = p * p;
     return ldexp(p, (int)k);
 }
+__device__ __forceinline__ double exp_m2n(double n, double y8max) { return exp_y8(n * -0.25, y8max); }
 
 // The reciprocal is v_rcp_f64 (4.5e-8) + one cubically convergent step.  Absolute error of
 // tansig vs the exact formula <= 1e-15.
@@ -186,6 +187,19 @@ __device__ __forceinline__ double tansig_den(double n)
 {
     return exp_m2n(n, 22.0) + 1.0;
 }
+// the same for the MFMA kernel, whose accumulators already hold y/8 = -n/4 (NetDev::bias_q)
+__device__ __forceinline__ double tansig_den_y8(double y8)
+{
+    return exp_y8(y8, 22.0) + 1.0;
+}
+__device__ __forceinline__ double tansig_y8(double y8)
+{
+    const double d = exp_y8(y8, 88.0) + 1.0;
+    double q = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, q, 1.0);
+    q = fma(q, fma(e, e, e), q);
+    return fma(2.0, q, -1.0);
+}
 
 // Four tansig values with ONE reciprocal: 1/d_i = (1 / (d0 d1 d2 d3)) * prod_{j != i} d_j.
 // v_rcp_f64 plus its refinement is 6 issue slots; sharing it costs 12 slots per four values
@@ -194,7 +208,7 @@ __device__ __forceinline__ double tansig_den(double n)
 // below 5e-16 relative.
 __device__ __forceinline__ void tansig4(double &v0, double &v1, double &v2, double &v3)
 {
-    const double d0 = tansig_den(v0), d1 = tansig_den(v1), d2 = tansig_den(v2), d3 = tansig_den(v3);
+    const double d0 = tansig_den_y8(v0), d1 = tansig_den_y8(v1), d2 = tansig_den_y8(v2), d3 = tansig_den_y8(v3);
     const double d01 = d0 * d1, d23 = d2 * d3;
     const double dd = d01 * d23;
     double q = __builtin_amdgcn_rcp(dd);
@@ -258,7 +272,7 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
             v += __shfl_xor(v, 32);
             pre = (q == 2 * j + u) ? v + bias[u] : pre;
         }
-    const double t = tansig(pre);
+    const double t = tansig_y8(pre);
     const double t1 = __shfl_xor(t, 32);
     out0 = d4{0.0, 0.0, 0.0, 0.0};
     out1 = d4{0.0, 0.0, 0.0, 0.0};
@@ -281,7 +295,7 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #elif SDPCUT_SMALL_IN_LDS
 #define BIAS_AT(i) s_bias[i]
 #else
-#define BIAS_AT(i) net.bias[i]
+#define BIAS_AT(i) net.bias_q[i]
 #endif
 #if SDPCUT_SMALL_IN_LDS
 #define WTAIL_AT(i) s_wtail[i]
@@ -290,7 +304,7 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #else
 #define WTAIL_AT(i) net.wtail[i]
 #define WOUT_AT(i) net.wout[i]
-#define BIAS_PTR net.bias
+#define BIAS_PTR net.bias_q
 #endif
 #ifdef SDPCUT_ABL_NOWLOAD
 #define WFRAG_AT(i) (0.01 * (double)((i) & 7))
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     __shared__ double s_wtail[NT ? NH * 4 * 64 : 1];
     __shared__ double s_wout[64];
     if (A.flags & SDPCUT_NN) {     // uniform; an eigenvalue-only launch may come without a network
-        for (int i = threadIdx.x; i < NH * 64; i += 256) s_bias[i] = net.bias[i];
+        for (int i = threadIdx.x; i < NH * 64; i += 256) s_bias[i] = net.bias_q[i];
         if constexpr (NT > 0)
             for (int i = threadIdx.x; i < NH * 4 * 64; i += 256) s_wtail[i] = net.wtail[i];
         if (threadIdx.x < 64) s_wout[threadIdx.x] = net.wout[threadIdx.x];
