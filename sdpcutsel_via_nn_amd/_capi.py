@@ -288,15 +288,19 @@ class Scorer(object):
             ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
         w, c = int(n_out.value), int(cap.value)
         if block.value and c:
-            nbytes = 64 + c * 8 * (4 + ld) + c * 4
-            buf = (_c.c_char * nbytes).from_address(block.value)
-            o = 64
-            idx = np.frombuffer(buf, dtype=np.int64, count=c, offset=o)[:w]; o += 8 * c
-            sc = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
-            lam = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
-            rhs = np.frombuffer(buf, dtype=np.float64, count=c, offset=o)[:w]; o += 8 * c
-            coef = np.frombuffer(buf, dtype=np.float64, count=c * ld, offset=o).reshape(c, ld)[:w]; o += 8 * c * ld
-            ks = np.frombuffer(buf, dtype=np.int32, count=c, offset=o)[:w]
+            key = (block.value, c, ld)
+            if getattr(self, "_round_view_key", None) != key:       # the block is reused round after round
+                nbytes = 64 + c * 8 * (4 + ld) + c * 4
+                buf = (_c.c_char * nbytes).from_address(block.value)
+                o = 64
+                v_idx = np.frombuffer(buf, dtype=np.int64, count=c, offset=o); o += 8 * c
+                v_sc = np.frombuffer(buf, dtype=np.float64, count=c, offset=o); o += 8 * c
+                v_lam = np.frombuffer(buf, dtype=np.float64, count=c, offset=o); o += 8 * c
+                v_rhs = np.frombuffer(buf, dtype=np.float64, count=c, offset=o); o += 8 * c
+                v_coef = np.frombuffer(buf, dtype=np.float64, count=c * ld, offset=o).reshape(c, ld); o += 8 * c * ld
+                v_ks = np.frombuffer(buf, dtype=np.int32, count=c, offset=o)
+                self._round_views, self._round_view_key = (v_idx, v_sc, v_lam, v_rhs, v_coef, v_ks), key
+            idx, sc, lam, rhs, coef, ks = (a[:w] for a in self._round_views)
             if copy:
                 idx, sc, lam, rhs, coef, ks = (a.copy() for a in (idx, sc, lam, rhs, coef, ks))
         else:
