@@ -713,3 +713,37 @@ def test_config4_shard_full_size_properties(lib, oracle):
         assert (lam < -1e-15).all() and np.abs(lam - eig[ref_order[:5000]]).max() <= 1e-15
     finally:
         sc.close()
+
+
+def test_repeated_rounds_are_deterministic(full_c2, scorer):
+    """300 back-to-back fused rounds with changing strategy / head length / point: every result is
+    bit-identical to the first one of its kind (double-buffered selection workspace, workspace
+    zeroing by the previous round's epilogue, early-stop path, pinned-block views)."""
+    from sdpcutsel_via_nn_amd import _capi
+    wl, _, _ = full_c2
+    scorer.set_instance(100, wl["Q_arr"])
+    scorer.set_candidates(wl["set_inds"], wl["ks"])
+    rng = np.random.default_rng(4)
+    points = [wl["vars_values"], np.clip(wl["vars_values"] + rng.normal(size=wl["vars_values"].shape) * 0.01, 0, 1)]
+    d_points = None
+    first = {}
+    for it in range(300):
+        p = int(rng.integers(0, 2))
+        strat = int(rng.choice([1, 2, 4]))
+        sel = int(rng.choice([1, 64, 777, 5000]))
+        scorer.set_point(points[p])
+        r = scorer.select_round(strat, sel, copy=False)
+        key = (p, strat, sel)
+        got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+        if key not in first:
+            first[key] = got
+            continue
+        ref = first[key]
+        for k, v in got.items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(v, ref[k], equal_nan=True), (it, key, k)
+            else:
+                assert v == ref[k], (it, key, k)
+    assert len(first) >= 20
+    scorer.set_point(wl["vars_values"])
+    scorer.score(_capi.EIG | _capi.NN)
