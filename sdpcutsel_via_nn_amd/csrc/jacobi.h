@@ -92,6 +92,101 @@ struct JacobiSweep {
     }
 };
 
+// ---- round-robin ("parallel") ordering: every stage rotates DISJOINT index pairs.  The angles of a
+// stage depend only on the 2x2 blocks of their own pairs, which the other rotations of the stage
+// do not touch, so they are computed side by side -- two or three independent sqrt / rcp / rsq
+// chains in flight instead of one -- and applied one after the other.  Branch-free (a negligible
+// a_pq gives the identity rotation) so that the compiler can interleave the chains.
+struct JacRot { double t, c, s, apq; };
+
+template <int D, int P, int Q>
+__device__ __forceinline__ JacRot jacobi_angle(const double (&a)[D][D])
+{
+    JacRot r;
+    r.apq = a[P][Q];
+    const bool act = fabs(r.apq) > 1e-140;
+    const double d = a[Q][Q] - a[P][P];
+    const double b = 2.0 * r.apq;
+    const double x = act ? fma(d, d, b * b) : 1.0;
+    const double den = d + copysign(jac_sqrt(x), d);
+    r.t = act ? b * jac_rcp(den) : 0.0;
+    r.c = jac_rsqrt(fma(r.t, r.t, 1.0));
+    r.s = r.t * r.c;
+    return r;
+}
+
+template <int D, int P, int Q, bool VEC>
+__device__ __forceinline__ void jacobi_apply(double (&a)[D][D], double (&v)[D][D], const JacRot &r)
+{
+    a[P][P] = fma(-r.t, r.apq, a[P][P]);
+    a[Q][Q] = fma(r.t, r.apq, a[Q][Q]);
+    a[P][Q] = 0.0;
+    a[Q][P] = 0.0;
+#pragma unroll
+    for (int r_ = 0; r_ < D; ++r_) {
+        if (r_ != P && r_ != Q) {
+            const double arp = a[r_][P], arq = a[r_][Q];
+            const double np_ = fma(r.c, arp, -r.s * arq);
+            const double nq_ = fma(r.s, arp, r.c * arq);
+            a[r_][P] = np_; a[P][r_] = np_;
+            a[r_][Q] = nq_; a[Q][r_] = nq_;
+        }
+    }
+    if (VEC) {
+#pragma unroll
+        for (int r_ = 0; r_ < D; ++r_) {
+            const double vrp = v[r_][P], vrq = v[r_][Q];
+            v[r_][P] = fma(r.c, vrp, -r.s * vrq);
+            v[r_][Q] = fma(r.s, vrp, r.c * vrq);
+        }
+    }
+}
+
+template <int D, bool VEC, int P0, int Q0, int P1, int Q1>
+__device__ __forceinline__ void jacobi_stage2(double (&a)[D][D], double (&v)[D][D])
+{
+    const JacRot r0 = jacobi_angle<D, P0, Q0>(a), r1 = jacobi_angle<D, P1, Q1>(a);
+    jacobi_apply<D, P0, Q0, VEC>(a, v, r0);
+    jacobi_apply<D, P1, Q1, VEC>(a, v, r1);
+}
+template <int D, bool VEC, int P0, int Q0, int P1, int Q1, int P2, int Q2>
+__device__ __forceinline__ void jacobi_stage3(double (&a)[D][D], double (&v)[D][D])
+{
+    const JacRot r0 = jacobi_angle<D, P0, Q0>(a), r1 = jacobi_angle<D, P1, Q1>(a), r2 = jacobi_angle<D, P2, Q2>(a);
+    jacobi_apply<D, P0, Q0, VEC>(a, v, r0);
+    jacobi_apply<D, P1, Q1, VEC>(a, v, r1);
+    jacobi_apply<D, P2, Q2, VEC>(a, v, r2);
+}
+
+// one sweep = every pair once, in a round-robin tournament schedule
+template <int D, bool VEC>
+__device__ __forceinline__ void jacobi_sweep_rr(double (&a)[D][D], double (&v)[D][D])
+{
+    if constexpr (D == 4) {
+        jacobi_stage2<D, VEC, 0, 1, 2, 3>(a, v);
+        jacobi_stage2<D, VEC, 0, 2, 1, 3>(a, v);
+        jacobi_stage2<D, VEC, 0, 3, 1, 2>(a, v);
+    } else if constexpr (D == 5) {
+        jacobi_stage2<D, VEC, 0, 1, 2, 3>(a, v);
+        jacobi_stage2<D, VEC, 0, 2, 1, 4>(a, v);
+        jacobi_stage2<D, VEC, 0, 3, 2, 4>(a, v);
+        jacobi_stage2<D, VEC, 0, 4, 1, 3>(a, v);
+        jacobi_stage2<D, VEC, 1, 2, 3, 4>(a, v);
+    } else if constexpr (D == 6) {
+        jacobi_stage3<D, VEC, 0, 1, 2, 3, 4, 5>(a, v);
+        jacobi_stage3<D, VEC, 0, 2, 1, 4, 3, 5>(a, v);
+        jacobi_stage3<D, VEC, 0, 3, 1, 5, 2, 4>(a, v);
+        jacobi_stage3<D, VEC, 0, 4, 1, 3, 2, 5>(a, v);
+        jacobi_stage3<D, VEC, 0, 5, 1, 2, 3, 4>(a, v);
+    } else {
+        JacobiSweep<D, 0, 1, VEC>::run(a, v);      // D = 3: no two disjoint pairs
+    }
+}
+
+#ifndef SDPCUT_JACOBI_RR
+#define SDPCUT_JACOBI_RR 1
+#endif
+
 // Diagonalises the symmetric matrix a (full storage, both triangles filled) in place.
 // On return the diagonal of a holds the eigenvalues (unsorted) and, if VEC, the columns
 // of v the corresponding orthonormal eigenvectors.
@@ -118,7 +213,11 @@ __device__ __forceinline__ void jacobi_eig(double (&a)[D][D], double (&v)[D][D])
 #pragma unroll
             for (int q = p + 1; q < D; ++q) off = fma(a[p][q], a[p][q], off);
         if (!(off > tol)) break;
+#if SDPCUT_JACOBI_RR
+        jacobi_sweep_rr<D, VEC>(a, v);
+#else
         JacobiSweep<D, 0, 1, VEC>::run(a, v);
+#endif
     }
 }
 
