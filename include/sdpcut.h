@@ -232,6 +232,12 @@ int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count,
 int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, int64_t count,
                                    const void *d_allrec, int64_t sel_size, int32_t coef_ld,
                                    const void **block);
+/* Same block, but the *n_own rows of THIS shard are moved to the front of lam_min / rhs / coef /
+ * ks (keeping head order) and an array  int32 pos[sel_size]  is appended behind ks: pos[j] = the
+ * position in the merged head of own row j.  idx / score stay the full replicated head. */
+int sdpcut_shard_finish_round_own(sdpcut_handle h, int32_t world, int64_t count,
+                                  const void *d_allrec, int64_t sel_size, int32_t coef_ld,
+                                  const void **block, int64_t *n_own);
 
 /*
  * Batched twin of _get_eigendecomp (cut_select_qp.py:788-797) for explicit sub-matrices:

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
+    "sdpcut_shard_finish_round_own": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p],
     "sdpcut_eig_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp, _dp, _dp],
     "sdpcut_nn_batch": [_vp, _c.c_int, _c.c_int64, _dp, _dp],
     "sdpcut_last_timing": [_vp, _dp, _c.c_int],
@@ -316,6 +317,24 @@ class Scorer(object):
         """enqueue this shard's packed head record (8 + 2*count int64 words); no host sync"""
         self._check(self._lib.sdpcut_shard_head_device(self._h, int(strat), int(count), _vp(d_record_ptr)))
 
+    def _shard_views(self, block, w, m, ld):
+        key = (block, w, m, ld)
+        if getattr(self, "_shard_view_key", None) != key:           # the block is reused round after round
+            nbytes = w * 64 + m * 8 * (4 + ld) + m * 8
+            buf = (_c.c_char * nbytes).from_address(block)
+            o = 0
+            hdr = np.frombuffer(buf, dtype=np.int64, count=w * 8, offset=o).reshape(w, 8); o += w * 64
+            idx = np.frombuffer(buf, dtype=np.int64, count=m, offset=o); o += 8 * m
+            sc = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+            lam = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+            rhs = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
+            coef = np.frombuffer(buf, dtype=np.float64, count=m * ld, offset=o).reshape(m, ld); o += 8 * m * ld
+            ks = np.frombuffer(buf, dtype=np.int32, count=m, offset=o); o += 4 * m
+            pos = np.frombuffer(buf, dtype=np.int32, count=m, offset=o)
+            self._shard_views_cache = dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks, pos=pos)
+            self._shard_view_key = key
+        return self._shard_views_cache
+
     def shard_finish_round(self, world, count, d_allrec_ptr, sel_size, copy=False):
         """merge the gathered records, cut rows of this shard's entries
         -> dict(headers [world, 8], idx, score, lam, coef, rhs, ks), each of sel_size entries:
@@ -325,18 +344,20 @@ class Scorer(object):
         block = _c.c_void_p()
         self._check(self._lib.sdpcut_shard_finish_round_view(
             self._h, w, int(count), _vp(d_allrec_ptr), m, ld, ctypes.byref(block)))
-        nbytes = w * 64 + m * 8 * (4 + ld) + m * 4
-        buf = (_c.c_char * nbytes).from_address(block.value)
-        o = 0
-        hdr = np.frombuffer(buf, dtype=np.int64, count=w * 8, offset=o).reshape(w, 8); o += w * 64
-        idx = np.frombuffer(buf, dtype=np.int64, count=m, offset=o); o += 8 * m
-        sc = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
-        lam = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
-        rhs = np.frombuffer(buf, dtype=np.float64, count=m, offset=o); o += 8 * m
-        coef = np.frombuffer(buf, dtype=np.float64, count=m * ld, offset=o).reshape(m, ld); o += 8 * m * ld
-        ks = np.frombuffer(buf, dtype=np.int32, count=m, offset=o)
-        out = dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks)
+        out = {k: v for k, v in self._shard_views(block.value, w, m, ld).items() if k != "pos"}
         return {k: v.copy() for k, v in out.items()} if copy else out
+
+    def shard_finish_round_own(self, world, count, d_allrec_ptr, sel_size):
+        """like shard_finish_round, but lam / coef / rhs / ks hold only the n_own rows of this shard
+        (compacted in head order by the library) and pos[:n_own] their positions in the head
+        -> dict(headers, idx, score, lam, coef, rhs, ks, pos, n_own); views, see above"""
+        m, ld, w = int(sel_size), self.row_len, int(world)
+        block, n_own = _c.c_void_p(), _c.c_int64(0)
+        self._check(self._lib.sdpcut_shard_finish_round_own(
+            self._h, w, int(count), _vp(d_allrec_ptr), m, ld, ctypes.byref(block), ctypes.byref(n_own)))
+        out = dict(self._shard_views(block.value, w, m, ld))
+        out["n_own"] = int(n_own.value)
+        return out
 
     # ------------------------------------------------------------------ triangle inequalities
     def tri_preprocess(self, adjacency):

@@ -121,7 +121,7 @@ extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, in
     const size_t ret_bytes = hdr_b + s * 8 * (4 + (size_t)coef_ld) + s * 4;
     int rc = ensure_stage(h, s * 16 + 64);
     if (rc) return rc;
-    rc = ensure_pinned(h, ret_bytes);
+    rc = ensure_pinned(h, ret_bytes + s * 4);      // + int32 pos[sel] of sdpcut_shard_finish_round_own
     if (rc) return rc;
     int64_t *d_mi = (int64_t *)h->d_stage;
     double *d_ms = (double *)(d_mi + s);
@@ -134,6 +134,37 @@ extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, in
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     *block = h->pinned;
+    return SDPCUT_OK;
+}
+
+// The same, with the rows of THIS shard compacted to the front of lam / rhs / coef / ks (head order)
+// and their positions in the head appended as int32 pos[sel]: the caller needs no mask arithmetic.
+extern "C" int sdpcut_shard_finish_round_own(sdpcut_handle h, int32_t world, int64_t count, const void *d_allrec,
+                                             int64_t sel_size, int32_t coef_ld, const void **block, int64_t *n_own)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!n_own) return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish_round arguments");
+    int rc = sdpcut_shard_finish_round_view(h, world, count, d_allrec, sel_size, coef_ld, block);
+    if (rc) return rc;
+    const size_t s = (size_t)sel_size, ld = (size_t)coef_ld;
+    char *p = (char *)h->pinned + (size_t)world * SHARD_HDR * 8 + s * 16;      // behind headers, ids, scores
+    double *lam = (double *)p;
+    double *rhs = lam + s;
+    double *coef = rhs + s;
+    int32_t *ks = (int32_t *)(coef + s * ld);
+    int32_t *pos = ks + s;
+    size_t w = 0;
+    for (size_t i = 0; i < s; ++i) {
+        if (ks[i] <= 0) continue;
+        if (w != i) {
+            lam[w] = lam[i];
+            rhs[w] = rhs[i];
+            std::memmove(coef + w * ld, coef + i * ld, ld * sizeof(double));
+            ks[w] = ks[i];
+        }
+        pos[w++] = (int32_t)i;
+    }
+    *n_own = (int64_t)w;
     return SDPCUT_OK;
 }
 

@@ -66,6 +66,10 @@ class DeviceOps(object):
     def shard_finish(self, world, count, allrec, sel_size):
         return self.scorer.shard_finish_round(world, count, allrec.data_ptr(), sel_size)
 
+    def shard_finish_own(self, world, count, allrec, sel_size):
+        """same, the own rows already compacted by the library (no mask arithmetic on the host)"""
+        return self.scorer.shard_finish_round_own(world, count, allrec.data_ptr(), sel_size)
+
     def rows_of(self, global_ids):
         """eigen-cut rows of the entries of ``global_ids`` (numpy) that live on this shard
         -> (mine mask, lam, coef [., row_len], rhs, ks)"""
@@ -189,7 +193,9 @@ class ShardedSelector(object):
 
         ``ids`` / ``scores`` are the replicated global head; ``mine`` marks the entries whose
         candidate lives on this rank, and lam/coef/rhs/ks hold the rows of exactly those (in head
-        order) -- every rank generates the rows of its own candidates, nothing else moves.
+        order) -- every rank generates the rows of its own candidates, nothing else moves.  The
+        row arrays are views of the handle's pinned host block (written by the device, compacted
+        by the library): valid until the next round on this selector.
 
         Common regime (strategies 1 and 2; strategy 4 with at least sel_size strong candidates
         overall): ONE collective and ONE host synchronisation per round -- the shard's head and
@@ -201,20 +207,28 @@ class ShardedSelector(object):
         ops = self.ops
         if 1 <= sel <= getattr(ops, "max_head", 0):
             rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel)
-            out = ops.shard_finish(self.world, sel, self._all_gather(rec), sel)
+            own = hasattr(ops, "shard_finish_own")
+            out = (ops.shard_finish_own if own else ops.shard_finish)(self.world, sel, self._all_gather(rec), sel)
             g = out["headers"].sum(axis=0)
             length = int(g[0])
             # g[4] != 0: some shard's selection gave up (csrc/topk.hip), its record is void
             if int(g[4]) == 0 and (strat != 4 or length >= sel):
                 valid = min(sel, length)
-                mine = out["ks"][:valid] > 0
                 cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))
                 if strat == 4:
                     cnt.update(strong=sel, violated=sel)
-                return dict(ids=out["idx"][:valid].copy(), scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
-                            mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
-                            rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine], new_strat=strat,
-                            n_total=self.n_global if strat != 1 else length, counters=cnt)
+                res = dict(ids=out["idx"][:valid].copy(), scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
+                           new_strat=strat, n_total=self.n_global if strat != 1 else length, counters=cnt)
+                if own:      # rows compacted by the library: views of its host block, valid until the next round
+                    w = out["n_own"]
+                    mine = np.zeros(valid, dtype=bool)
+                    mine[out["pos"][:w]] = True
+                    res.update(mine=mine, lam=out["lam"][:w], coef=out["coef"][:w], rhs=out["rhs"][:w], ks=out["ks"][:w])
+                else:
+                    mine = out["ks"][:valid] > 0
+                    res.update(mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
+                               rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine])
+                return res
         res = self.select(strat, sel_size)
         ids = res["ids"].cpu().numpy()
         mine, lam, coef, rhs, ks = ops.rows_of(ids)
