@@ -608,7 +608,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     const int64_t *d_cnt = nullptr;
     rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, keys_done);
     if (rc < 0) return rc;
-    if (rc == 1) {
+    const bool fast_tried = rc == 1;
+    if (fast_tried) {
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
         rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev);
         if (rc) return rc;
@@ -617,7 +618,10 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     }
     if (!have) {
         // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
-        rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters);
+        // (the fast attempt above already counted the strong candidates: no second attempt)
+        const int64_t *c5 = (const int64_t *)h->pinned;
+        const int64_t hint = (fast_tried && strat == SDPCUT_STRAT_COMB && !c5[4]) ? c5[0] : -1;
+        rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters, hint);
         if (rc) return rc;
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
         if (w > 0) {

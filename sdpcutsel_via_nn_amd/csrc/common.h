@@ -141,7 +141,7 @@ int launch_mfma_probe(sdpcut_ctx *h, const double *d_A, const double *d_B, doubl
 int ensure_rank_ws(sdpcut_ctx *h, int64_t n);
 int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
                    double *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
-                   int64_t *counters);
+                   int64_t *counters, int64_t strong_hint = -1);
 int merge_topk_on_device(sdpcut_ctx *h, int64_t count, const double *d_scores, const double *d_secondary,
                          const int64_t *d_ids, int64_t max_out, double *d_score_out, int64_t *d_id_out);
 int gather_scores_on_device(sdpcut_ctx *h, int64_t count, const int64_t *d_ids, double *d_eig_out, double *d_obj_out);

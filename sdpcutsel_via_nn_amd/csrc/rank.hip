@@ -231,7 +231,7 @@ int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out
 
 int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
                    double *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
-                   int64_t *counters_out)
+                   int64_t *counters_out, int64_t strong_hint)
 {
     const int64_t n = h->N;
     int rc = ensure_rank_ws(h, n);
@@ -239,8 +239,10 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     if (sel_size > n) sel_size = n;                 // cut_select_qp.py:551
     if (sel_size < 0) sel_size = 0;
     int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // ---- fast path: the caller wants only a short head (topk.hip)
-    {
+    // ---- fast path: the caller wants only a short head (topk.hip).  strong_hint >= 0: the caller
+    // has just tried it and learnt that only strong_hint < sel_size candidates are strong.
+    int64_t strong = strong_hint;
+    if (strong < 0) {
         const int64_t *d_c4 = nullptr;
         rc = rank_fast_enqueue(h, strat, sel_size, max_out, d_idx_out, d_score_out, &d_c4);
         if (rc < 0) return rc;
@@ -249,7 +251,33 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
             HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             if (rank_fast_finish(h, strat, sel_size, max_out, c4, n_written, n_total, new_strat, counters_out)) return 0;
-            // fewer strong candidates than sel_size: every entry is visited -> general path below
+            // fewer strong candidates than sel_size: every entry is visited
+            if (!c4[4] && strat == SDPCUT_STRAT_COMB) strong = c4[0];
+        }
+    }
+    // ---- combined scan that visits EVERY entry (strong < sel_size): the new score of an entry is
+    // then a function of its own (obj_improve, eigmin) alone (cut_select_qp.py:606-623), and the head
+    // of the re-sorted list is a top-k by (new score, obj_improve, index) -- radix select again, with
+    // obj_improve as secondary key where new scores tie (second stable sort of :625).
+    if (strat == SDPCUT_STRAT_COMB && strong >= 0 && strong < sel_size && n > 0 && max_out >= 1 && max_out <= 8192) {
+        const int64_t *d_c4 = nullptr;
+        rc = topk_select_enqueue(h, 4 /* TK_MODE_COMBALL */, max_out, 0.0, d_idx_out, d_score_out, &d_c4);
+        if (rc) return rc;
+        int64_t c4[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!c4[4]) {       // (void: more equal new scores at the threshold than the sort buffers hold)
+            const int64_t w = n < max_out ? n : max_out;
+            h->last_total = -1;
+            if (n_written) *n_written = w;
+            if (n_total) *n_total = n;
+            // every violated entry is seen by the scan: violated_in_scan = nb_violated
+            const int64_t c[4] = {c4[1], strong, c4[1], c4[2]};
+            if (new_strat)
+                *new_strat = ((double)c[1] / (double)sel_size < (double)c[2] / (double)n) ? SDPCUT_STRAT_FEAS : SDPCUT_STRAT_COMB;
+            if (counters_out)
+                for (int i = 0; i < 4; ++i) counters_out[i] = c[i];
+            return 0;
         }
     }
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 8 * sizeof(int64_t), h->stream));

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         __syncthreads();
         if (threadIdx.x < 3 && tk_cnt[threadIdx.x])
             atomicAdd((unsigned long long *)&A.tk->counters[threadIdx.x], (unsigned long long)tk_cnt[threadIdx.x]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) st_i64(&A.tk->mode, A.tk_mode);
         finish_pass(A.tk, 0, A.tk_k, tk_hist, A.tk_blocks);
     }
 }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
             if (in) {
                 key = masked_key(mode, e[u], o[u]);
                 keys[idx[u]] = key;
-                c_class += (mode == TK_MODE_OPT) ? 1u : (key != 0ull);
+                c_class += (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? 1u : (key != 0ull);
                 c_viol += (eig != nullptr) && (e[u] < SDPCUT_NEG_EIGVAL);
                 c_pos += (obj != nullptr) && (o[u] > 0.0);
             }
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
     __syncthreads();
     if (threadIdx.x < 3 && cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&ws->counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st_i64(&ws->mode, mode);
     finish_pass(ws, 0, k, hist, gridDim.x);
 }
 
@@ -263,14 +264,22 @@ __global__ __launch_bounds__(TK_THREADS) void tk_write_kernel(int64_t n, int64_t
 // ~k log k work instead of the k^2 of a counting sort, two short launches.
 #define TK_TILE 512
 
-__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib)
+// obj != NULL (mode COMBALL): equal keys are ordered by obj_improve descending before the index --
+// the first stable sort of the reference (:601) under its second one (:625).  The scores are only
+// fetched for equal keys (rare unless the point is degenerate); padding never reaches the fetch.
+__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, const double *obj = nullptr)
 {
-    return (ka < kb) || (ka == kb && ia < ib);
+    if (ka != kb) return ka < kb;
+    if (obj && ia != 0xffffffffu && ib != 0xffffffffu) {
+        const uint64_t oa = key_of(obj[ia]), ob = key_of(obj[ib]);
+        if (oa != ob) return oa > ob;
+    }
+    return ia < ib;
 }
 
 __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *ws, const uint64_t *sel_key,
                                                                  const uint32_t *sel_idx, uint64_t *tile_key,
-                                                                 uint32_t *tile_idx)
+                                                                 uint32_t *tile_idx, const double *obj)
 {
     __shared__ uint64_t sk[TK_TILE];
     __shared__ uint32_t si[TK_TILE];
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
             const bool up = (pos & size) == 0;
             const uint64_t ka = sk[pos], kb = sk[par];
             const uint32_t ia = si[pos], ib = si[par];
-            if (comp_less(kb, ib, ka, ia) == up) {
+            if (comp_less(kb, ib, ka, ia, obj) == up) {
                 sk[pos] = kb; sk[par] = ka;
                 si[pos] = ib; si[par] = ia;
             }
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
 
 __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
                                                                   const uint64_t *tile_key, const uint32_t *tile_idx,
-                                                                  int64_t *idx_out, double *score_out)
+                                                                  int64_t *idx_out, double *score_out, const double *obj)
 {
     __shared__ uint64_t sk[TK_MAXK];
     __shared__ uint32_t si[TK_MAXK];
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
         int lo = 0, hi = TK_TILE;
         while (lo < hi) {                                     // <= 10 steps
             const int mid = (lo + hi) >> 1;
-            const bool less = comp_less(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie);
+            const bool less = comp_less(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie, obj);
             lo = less ? mid + 1 : lo;
             hi = less ? hi : mid;
         }
@@ -431,10 +440,11 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;
     uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
+    const double *tie_obj = (mode == TK_MODE_COMBALL) ? h->d_obj : nullptr;
     hipLaunchKernelGGL(tk_tilesort_kernel, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key, h->d_sel_idx,
-                       tile_key, tile_idx);
+                       tile_key, tile_idx, tie_obj);
     hipLaunchKernelGGL(tk_mergerank_kernel, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                       h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out);
+                       h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
     HIP_TRY(h, hipGetLastError());
     if (d_counters_out) *d_counters_out = ws->counters;
     return 0;

@@ -12,7 +12,9 @@
 #define TK_MAXK 8192
 #define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
 
-enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3 };
+// 4: combined strategy when the scan visits every entry -- the key is the new score of
+// cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
+enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3, TK_MODE_COMBALL = 4 };
 
 struct TkState {
     uint64_t prefix;   // digits resolved so far, in place
@@ -29,6 +31,7 @@ struct TopkWs {
     uint32_t blk_eq[TK_MAXBLK];
     uint32_t blk_gt[TK_MAXBLK];
     int64_t n_sel;           // entries compacted by tk_write_kernel (>= k_eff after an early stop)
+    int64_t mode;            // TK_MODE_* of the running selection (written by its pass 0)
     uint32_t ready[9];       // tk_hist_rest_kernel: state[p] has been published inside the launch
     uint32_t pad_[1];
 };
@@ -95,7 +98,12 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
             const int64_t k_eff = ld_i64(&ws->counters[3]);
             const int64_t in_bin = here - above;
             const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
-            if (p < 7 && superset <= TK_MAXK) {
+            // Mode COMBALL cannot cut a group of equal keys by index (their order is by obj_improve):
+            // at the last digit it either takes the whole group too, or declares the selection void
+            // (counters[4]) and the host sorts the full list.
+            const bool comball = ld_i64(&ws->mode) == TK_MODE_COMBALL;
+            if (p == 7 && comball && in_bin > need - above && superset > TK_MAXK) st_i64(&ws->counters[4], 2);
+            if ((p < 7 || comball) && superset <= TK_MAXK) {
                 for (int qq = p + 1; qq <= 8; ++qq) {
                     st_i64((int64_t *)&ws->state[qq].prefix, (int64_t)pre);
                     st_i64(&ws->state[qq].need, in_bin);   // every key equal to the bin's lowest value, if any
@@ -151,6 +159,12 @@ __device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
 {
     if (mode == TK_MODE_OPT) return key_of(obj);
     const bool viol = eig < SDPCUT_NEG_EIGVAL;
+    if (mode == TK_MODE_COMBALL) {      // same arithmetic as comb_keys_kernel (rank.hip) for a visited entry
+        double s = obj;
+        if (s > 0.0) s = viol ? s + SDPCUT_BIG_M : s - SDPCUT_BIG_M;
+        else if (viol) s = -eig;
+        return key_of(s);
+    }
     if (mode == TK_MODE_FEAS) return viol ? key_of(-eig) : 0ull;
     return (obj > 0.0 && viol) ? key_of(obj) : 0ull;
 }

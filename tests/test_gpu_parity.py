@@ -747,3 +747,50 @@ def test_repeated_rounds_are_deterministic(full_c2, scorer):
     assert len(first) >= 20
     scorer.set_point(wl["vars_values"])
     scorer.score(_capi.EIG | _capi.NN)
+
+
+@pytest.mark.parametrize("count", [3000, 60000, 1000000])
+def test_combined_all_visited_ties_by_obj_improve(full_c2, scorer, oracle, count):
+    """Combined strategy with fewer strong candidates than sel_size at a structured point: the
+    re-sorted list is headed by violated candidates whose new score is -lambda_min, shared by
+    whole groups of candidates and ordered inside a group by obj_improve (first sort), then index.
+    Small lists resolve this in the radix-select path (secondary key), large groups overflow its
+    buffers and go through the full sorts -- both must equal the oracle."""
+    from sdpcutsel_via_nn_amd import _capi
+    wl, _, _ = full_c2
+    n = 100
+    scorer.set_instance(n, wl["Q_arr"])
+    scorer.set_candidates(wl["set_inds"][:count], wl["ks"][:count])
+    X = np.full((n, n), 0.1)
+    for v in range(12):
+        X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+    vv = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+    try:
+        scorer.set_point(vv)
+        scorer.score(_capi.EIG | _capi.NN)
+        eig, obj = scorer.get_scores()
+        n_strong = int(((obj > 0) & (eig < -1e-15)).sum())
+        groups = np.unique(eig, return_counts=True)[1]
+        assert groups.max() > 50
+        ran = 0
+        for sel in (n_strong + 1, n_strong + 700, min(count, 5000), min(count, 8192)):
+            if sel <= n_strong or sel > count:
+                continue
+            ran += 1
+            order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(4, obj, eig, sel)
+            for max_out in (sel, 37):
+                ids, score, total, new_strat, cnt = scorer.rank(4, sel, max_out=max_out)
+                assert np.array_equal(ids, order[:max_out]), (count, sel, max_out)
+                assert np.array_equal(score, ref_score[:max_out] + 0.0)
+                assert new_strat == ref_strat and total == count
+                assert cnt["strong"] == ref_cnt["strong"] and cnt["violated"] == ref_cnt["violated"]
+            scorer.set_point(vv)
+            r = scorer.select_round(4, sel)
+            assert np.array_equal(r["idx"], order[:sel]) and np.array_equal(r["score"], ref_score[:sel] + 0.0)
+            assert r["new_strat"] == ref_strat and r["counters"]["strong"] == ref_cnt["strong"]
+            scorer.score(_capi.EIG | _capi.NN)
+        assert ran >= 2, (n_strong, count)
+    finally:
+        scorer.set_candidates(wl["set_inds"], wl["ks"])
+        scorer.set_point(wl["vars_values"])
+        scorer.score(_capi.EIG | _capi.NN)
