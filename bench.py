@@ -48,9 +48,21 @@ def cpu_baseline(wl, sample):
     for c in order[:min(SEL, sample)][:SEL]:
         w, v = oracle.get_eigendecomp(K, vv[L:][si[c]], vv[:L][oracle.triu_positions(si[c], NB_VARS)], True)
     dt = time.perf_counter() - t0
+    # the reference's own shape -- a Python loop with one ctypes call
+    # into the NNs.so-compatible entry point and one LAPACK eigvalsh per candidate -- on a small
+    # sub-sample (optimality list + feasibility list = both measures for every candidate)
+    m = min(20000, sample)
+    agg = oracle.build_agg_list([tuple(int(v) for v in s) for s in si[:m]], NB_VARS, Q)
+    t1 = time.perf_counter()
+    oracle.sel_eigcut_by_ordering_on_measure(agg, L, 2, vv)
+    oracle.sel_eigcut_by_ordering_on_measure(agg, L, 1, vv)
+    dt_loop = time.perf_counter() - t1
     return dict(value=sample / dt, unit="candidates/s", cores=1, kind="port",
                 sample="first %d of the %d candidates of this workload, same round (score eig+NN, combined "
-                       "ranking, %d eigh cut rows), %.1f s" % (sample, N_PER_GPU, min(SEL, sample), dt))
+                       "ranking, %d eigh cut rows), %.1f s" % (sample, N_PER_GPU, min(SEL, sample), dt),
+                reference_style_loop=dict(value=m / dt_loop, unit="candidates/s", cores=1,
+                                          sample="per-candidate Python loop (ctypes NN + eigvalsh each) on the "
+                                                 "first %d candidates, %.1f s" % (m, dt_loop)))
 
 
 def main():
