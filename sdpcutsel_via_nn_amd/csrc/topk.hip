@@ -411,6 +411,52 @@ int topk_begin(sdpcut_ctx *h, void **ws_out, uint64_t **keys_out)
     return 0;
 }
 
+// Lists that fit the sort buffers whole (n <= 8192 -- most of the reference's BoxQP / QCQP instances)
+// need no radix passes: ONE workgroup builds the keys, counts the class and compacts its members;
+// the sort that follows orders all of them and emits the first k_eff.  Three launches instead of
+// seven on the latency-bound end of the problem sizes.
+__global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t n, int64_t k, const double *eig,
+                                                              const double *obj, TopkWs *ws, uint64_t *sel_key,
+                                                              uint32_t *sel_idx)
+{
+    __shared__ uint32_t cnt[4];      // class members, violated, positive, next slot
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = 0; i0 < n; i0 += TK_THREADS) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const double e = (in && eig) ? eig[i] : 0.0, o = (in && obj) ? obj[i] : 0.0;
+        const uint64_t key = in ? masked_key(mode, e, o) : 0ull;
+        const bool member = in && ((mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? true : key != 0ull);
+        const unsigned long long mm = __ballot(member);
+        const unsigned long long mv = __ballot(in && eig != nullptr && e < SDPCUT_NEG_EIGVAL);
+        const unsigned long long mp = __ballot(in && obj != nullptr && o > 0.0);
+        uint32_t base = 0;
+        if (lane == 0) {
+            if (mm) base = atomicAdd(&cnt[3], (uint32_t)__popcll(mm));
+            if (mv) atomicAdd(&cnt[1], (uint32_t)__popcll(mv));
+            if (mp) atomicAdd(&cnt[2], (uint32_t)__popcll(mp));
+        }
+        base = (uint32_t)__shfl((int)base, 0);
+        if (member) {
+            const uint32_t slot = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+            sel_key[slot] = key;
+            sel_idx[slot] = (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t cls = cnt[3];
+        ws->counters[0] = cls;
+        ws->counters[1] = cnt[1];
+        ws->counters[2] = cnt[2];
+        ws->counters[3] = k < cls ? k : cls;
+        ws->n_sel = cls;
+        ws->mode = mode;
+    }
+}
+
 // keys_done: the score kernels already ran pass 0 (keys, leading digit, class counters) on the
 // workspace handed out by topk_begin.
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
@@ -428,15 +474,20 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
-    if (!keys_done)
-        hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
-    hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
-    hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
-    int64_t chunk = (n + grid - 1) / grid;
-    chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
-    hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
-    hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
-                       h->d_sel_key, h->d_sel_idx);
+    if (!keys_done && n <= TK_MAXK) {
+        hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, ws, h->d_sel_key,
+                           h->d_sel_idx);
+    } else {
+        if (!keys_done)
+            hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
+        hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
+        hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
+        int64_t chunk = (n + grid - 1) / grid;
+        chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
+        hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
+        hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
+                           h->d_sel_key, h->d_sel_idx);
+    }
     const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;
     uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
