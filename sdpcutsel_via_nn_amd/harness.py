@@ -47,7 +47,7 @@ class _RowStore(object):
         start, r = self._n, len(indptr) - 1
         self._blocks.append(("csr", np.asarray(indptr), np.asarray(indices), np.asarray(values)))
         self._n += r
-        self.rhs.extend(float(v) for v in rhs)
+        self.rhs.extend(np.asarray(rhs, dtype=np.float64).tolist())
         self.senses.extend([sense] * r)
         return range(start, self._n)
 
