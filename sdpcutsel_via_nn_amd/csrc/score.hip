@@ -150,10 +150,17 @@ __device__ __forceinline__ double tansig_lib(double n)
 //    degree-8 Taylor polynomial with one FMA less;
 //  * only the upper clamp is needed (y8max = 88 keeps exp finite; towards -inf ldexp underflows
 //    to 0 and tansig saturates at +1 by itself).
-__device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(8 y8_in), y8_in = -n / 4
+//  * k is rounded with the 1.5 * 2^52 trick: the low dword of t IS k as an int32 (|k| < 2^31, i.e.
+//    |y| < 1.4e9 -- pre-activations of these networks stay below 1e3), which saves the
+//    double->int conversion; with the constant lowered by SHIFT the dword holds k - SHIFT, so
+//    exp(y) / 2 (SHIFT = 1, what tansig4/tansig8 want) costs nothing extra and is exact.
+template <int SHIFT>
+__device__ __forceinline__ double exp_y8_scaled(double y8_in, double y8max)     // exp(8 y8_in) / 2^SHIFT
 {
+    constexpr double MAGIC = 0x1.8p52 - (double)SHIFT;
     const double y8 = fmin(y8_in, y8max);
-    const double k = rint(y8 * 11.541560327111707259);               // 8 log2 e
+    const double t = fma(y8, 11.541560327111707259, MAGIC);         // 8 log2 e
+    const double k = t - MAGIC;
     const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)
     double p = 0x1.a02041015378fp-13;
     p = fma(p, r, 0x1.6c1d00cea5bf1p-10);
@@ -166,7 +173,11 @@ __device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(
     p = p * p;
     p = p * p;
     p = p * p;
-    return ldexp(p, (int)k);
+    return ldexp(p, __double2loint(t));
+}
+__device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(8 y8_in), y8_in = -n / 4
+{
+    return exp_y8_scaled<0>(y8_in, y8max);
 }
 __device__ __forceinline__ double exp_m2n(double n, double y8max) { return exp_y8(n * -0.25, y8max); }
 
@@ -181,18 +192,7 @@ __device__ __forceinline__ double tansig(double n)
     return fma(2.0, q, -1.0);
 }
 
-// exp(-2n) + 1, the denominator of tansig, for tansig4.  y = -2n is clamped to 176 here so that
-// the product of four denominators stays finite (tansig(-88) is -1 to 2e-76 either way).
-__device__ __forceinline__ double tansig_den(double n)
-{
-    return exp_m2n(n, 22.0) + 1.0;
-}
-// the same for the MFMA kernel, whose accumulators already hold y/8 = -n/4 (NetDev::bias_q)
-__device__ __forceinline__ double tansig_den_y8(double y8)
-{
-    return exp_y8(y8, 22.0) + 1.0;
-}
-__device__ __forceinline__ double tansig_y8(double y8)
+__device__ __forceinline__ double tansig_y8(double y8)  // the accumulators of the MFMA kernel hold y/8 = -n/4 (NetDev::bias_q)
 {
     const double d = exp_y8(y8, 88.0) + 1.0;
     double q = __builtin_amdgcn_rcp(d);
@@ -201,21 +201,33 @@ __device__ __forceinline__ double tansig_y8(double y8)
     return fma(2.0, q, -1.0);
 }
 
-// Four tansig values with ONE reciprocal: 1/d_i = (1 / (d0 d1 d2 d3)) * prod_{j != i} d_j.
-// v_rcp_f64 plus its refinement is 6 issue slots; sharing it costs 12 slots per four values
-// instead of 24 (the kernel is bound by the VALU/MFMA instruction count).  Every d_i >= 1 and
-// <= 1 + e^176, so the product neither underflows nor overflows; the extra roundings stay
-// below 5e-16 relative.
+// HALF the denominator of tansig, h = (exp(-2n) + 1) / 2, so that tansig = 1/h - 1 (the factor 2
+// of the formula is absorbed exactly by the exponent shift of exp_y8_scaled<1>).
+__device__ __forceinline__ double tansig_hden_y8(double y8, double y8max)
+{
+    return exp_y8_scaled<1>(y8, y8max) + 0.5;
+}
+
+// Four tansig values with ONE reciprocal: 1/h_i = (1 / (h0 h1 h2 h3)) * prod_{j != i} h_j.
+// v_rcp_f64 plus its refinement is 6 issue slots (the kernel is bound by the VALU/MFMA
+// instruction count): shared by four values the reciprocal part costs 3.5 slots per value
+// instead of 7, and the halved denominators drop the doubling.  Every h_i is >= 1/2 and
+// <= (1 + e^176) / 2 (y = -2n clamped to 176: tansig(-88) is -1 to 2e-76 either way), so the
+// product neither underflows nor overflows; the extra roundings stay below 5e-16 relative.
+// The four values are four neurons of ONE candidate (the rows of a C/D fragment), so a
+// candidate's score does not depend on its neighbours in the wave.  (Sharing over the eight
+// values of the two column tiles saved another 0.7 % but made duplicates of a candidate differ
+// in the last bit depending on their position -- ties would no longer break by index.)
 __device__ __forceinline__ void tansig4(double &v0, double &v1, double &v2, double &v3)
 {
-    const double d0 = tansig_den_y8(v0), d1 = tansig_den_y8(v1), d2 = tansig_den_y8(v2), d3 = tansig_den_y8(v3);
+    const double d0 = tansig_hden_y8(v0, 22.0), d1 = tansig_hden_y8(v1, 22.0);
+    const double d2 = tansig_hden_y8(v2, 22.0), d3 = tansig_hden_y8(v3, 22.0);
     const double d01 = d0 * d1, d23 = d2 * d3;
     const double dd = d01 * d23;
     double q = __builtin_amdgcn_rcp(dd);
     const double e = fma(-dd, q, 1.0);
     q = fma(q, fma(e, e, e), q);
-    q = q + q;
-    const double q01 = q * d23, q23 = q * d01;          // 2/(d0 d1), 2/(d2 d3)
+    const double q01 = q * d23, q23 = q * d01;          // 1/(h0 h1), 1/(h2 h3)
     v0 = fma(q01, d1, -1.0);
     v1 = fma(q01, d0, -1.0);
     v2 = fma(q23, d3, -1.0);
