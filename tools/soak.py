@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Soak run on the GPU box: thousands of back-to-back fused rounds over changing points (random
+LP-like points and structured points whose masses of equal eigenvalues drive the radix select
+through all eight digits inside the grid barrier), strategies, head lengths and list sizes.
+Every result must be bit-identical to the first one of its kind.
+Usage: python tools/soak.py [seconds=120] [count=1000000]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sdpcutsel_via_nn_amd import _capi, networks, synthetic  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 10 ** 6
+    n = 100
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=count, seed=7)
+    sc = _capi.Scorer(0)
+    sc.set_network(3, *networks.load_network(3))
+    sc.set_instance(n, wl["Q_arr"])
+    rng = np.random.default_rng(11)
+    points = [wl["vars_values"], np.clip(wl["vars_values"] + rng.normal(size=wl["vars_values"].shape) * 0.01, 0, 1)]
+    for distinct in (0, 3, 12):            # structured: a handful of eigenvalues shared by 1e4..1e6 candidates
+        X = np.full((n, n), 0.1)
+        for v in range(distinct):
+            X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+        points.append(np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)]))
+    sizes = [count, max(count // 7, 1), 8192, 5000, 300]
+    first, rounds, per_kind = {}, 0, {}
+    t_end = time.time() + budget
+    cur_size = None
+    while time.time() < t_end:
+        size = int(rng.choice(sizes))
+        if size != cur_size:
+            sc.set_candidates(wl["set_inds"][:size], wl["ks"][:size])
+            cur_size = size
+        for _ in range(40):
+            p = int(rng.integers(0, len(points)))
+            strat = int(rng.choice([1, 2, 4]))
+            sel = int(rng.choice([1, 64, 777, 5000]))
+            sc.set_point(points[p])
+            r = sc.select_round(strat, sel, copy=False)
+            key = (size, p, strat, sel)
+            got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+            rounds += 1
+            per_kind[key] = per_kind.get(key, 0) + 1
+            if key not in first:
+                first[key] = got
+                continue
+            ref = first[key]
+            for k, v in got.items():
+                same = np.array_equal(v, ref[k], equal_nan=True) if isinstance(v, np.ndarray) else v == ref[k]
+                if not same:
+                    print("MISMATCH round %d kind %s field %s" % (rounds, key, k), flush=True)
+                    sys.exit(1)
+        if rounds % 2000 < 40:
+            print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
+    print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4), every repeat bit-identical"
+          % (rounds, len(first), sizes, len(points)))
+    sc.close()
+
+
+if __name__ == "__main__":
+    main()
