@@ -341,6 +341,17 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
     printf("blk %d wave %d tiles %d: gather %llu jacobi %llu stage %llu mlp %llu cycles/tile\n", (int)blockIdx.x, \
            (int)(threadIdx.x >> 6), ph_n, ph_acc[0] / (ph_n ? ph_n : 1), ph_acc[1] / (ph_n ? ph_n : 1),      \
            ph_acc[2] / (ph_n ? ph_n : 1), ph_acc[3] / (ph_n ? ph_n : 1))
+#elif defined(SDPCUT_ABL_CLOCKS)
+// shader clock actually sustained while the kernel runs: core-clock counter against the 100 MHz one
+#define PHASE_DECL const unsigned long long ph_c0 = clock64(), ph_w0 = wall_clock64()
+#define PHASE_MARK(i)
+#define PHASE_WAITMEM
+#define PHASE_REPORT                                                                                         \
+    if (threadIdx.x == 0 && (blockIdx.x % 509) == 3) {                                                       \
+        const unsigned long long dc = clock64() - ph_c0, dw = wall_clock64() - ph_w0;                        \
+        printf("blk %d: %llu core cycles in %llu ticks of 10 ns -> %.0f MHz\n", (int)blockIdx.x, dc, dw,     \
+               dw ? 100.0 * (double)dc / (double)dw : 0.0);                                                  \
+    }
 #else
 #define PHASE_DECL
 #define PHASE_MARK(i)

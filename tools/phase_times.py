@@ -16,7 +16,7 @@ sc.set_network(k, *networks.load_network(k))
 sc.set_instance(100, wl["Q_arr"])
 sc.set_candidates(wl["set_inds"], wl["ks"])
 sc.set_point(wl["vars_values"])
-for it in range(3):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
     sc.score(_capi.EIG | _capi.NN)
     print("launch", it, "kernel %.1f us" % (1e3 * sc.last_timing()[0]), flush=True)
 sc.close()
