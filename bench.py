@@ -91,11 +91,18 @@ def main():
     # SDPCUT_BENCH_FORCE_SHARDED=1: run the N > 1 code path (packed head, finish) at N = 1 to see
     # what it costs over the fused single-GPU round, the collective itself excluded
     force_sharded = os.environ.get("SDPCUT_BENCH_FORCE_SHARDED") == "1"
+    # SDPCUT_FORCE_COLLECTIVES=1 (under `torch.distributed.run --nproc-per-node 1`): rehearse the N > 1
+    # path against real RCCL on a one-GPU box -- process group, barrier, all-gather, all-reduce with
+    # one rank
+    solo_dist = world == 1 and os.environ.get("SDPCUT_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
+    if solo_dist:
+        force_sharded = True
     if os.environ.get("SDPCUT_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or solo_dist
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -104,7 +111,7 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from sdpcutsel_via_nn_amd import _capi, networks, synthetic
@@ -161,17 +168,17 @@ def main():
     for _ in range(args.warmup):
         step()
     del kernel_ms[:]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res, rows = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -204,7 +211,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, N_PER_GPU))
         print(json.dumps(out), flush=True)
     sc.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

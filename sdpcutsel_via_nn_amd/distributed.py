@@ -15,6 +15,8 @@ candidates) with one collective and one host synchronisation (csrc/shard.hip).
 With the "gloo" backend (CPU rehearsal of the choreography, used by the tests) the gathered
 buffers are staged through host memory; the ranking and the merge still run on the device.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -94,12 +96,16 @@ class ShardedSelector(object):
         self.ops, self.group = ops, group
         self._gathered = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # rehearsal on a one-GPU box (SDPCUT_FORCE_COLLECTIVES=1 under torch.distributed.run with one
+        # rank): run the collectives even though there is nobody to talk to, so that the RCCL calls,
+        # dtypes and stream hand-offs of the N > 1 path are exercised for real
+        self._solo = self.world == 1 and not (dist.is_initialized() and os.environ.get("SDPCUT_FORCE_COLLECTIVES") == "1")
         self.n_local = int(n_local)
         self.n_global = self._sum(self.n_local)
 
     # -- collectives ---------------------------------------------------------------------
     def _sum(self, *vals):
-        if self.world == 1:
+        if self._solo:
             return vals[0] if len(vals) == 1 else list(vals)
         t = torch.tensor(vals, dtype=torch.int64)
         if dist.get_backend(self.group) == "nccl":
@@ -109,7 +115,7 @@ class ShardedSelector(object):
         return out[0] if len(vals) == 1 else out
 
     def _all_gather(self, t):
-        if self.world == 1:
+        if self._solo:
             return t
         if dist.get_backend(self.group) == "nccl":
             key = (t.numel(), t.dtype)
