@@ -68,8 +68,8 @@ def cpu_baseline(wl, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
