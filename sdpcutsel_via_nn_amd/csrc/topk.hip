@@ -267,16 +267,24 @@ __global__ __launch_bounds__(TK_THREADS) void tk_write_kernel(int64_t n, int64_t
 // obj != NULL (mode COMBALL): equal keys are ordered by obj_improve descending before the index --
 // the first stable sort of the reference (:601) under its second one (:625).  The scores are only
 // fetched for equal keys (rare unless the point is degenerate); padding never reaches the fetch.
-__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, const double *obj = nullptr)
+// The sort kernels are instantiated twice: TIE = false is the plain composite compare (a memory
+// fetch and a branch inside the comparator cost the common modes 30 % of both kernels).
+template <bool TIE>
+__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, const double *obj)
 {
-    if (ka != kb) return ka < kb;
-    if (obj && ia != 0xffffffffu && ib != 0xffffffffu) {
-        const uint64_t oa = key_of(obj[ia]), ob = key_of(obj[ib]);
-        if (oa != ob) return oa > ob;
+    if constexpr (!TIE) {
+        return ka < kb || (ka == kb && ia < ib);
+    } else {
+        if (ka != kb) return ka < kb;
+        if (ia != 0xffffffffu && ib != 0xffffffffu) {
+            const uint64_t oa = key_of(obj[ia]), ob = key_of(obj[ib]);
+            if (oa != ob) return oa > ob;
+        }
+        return ia < ib;
     }
-    return ia < ib;
 }
 
+template <bool TIE>
 __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *ws, const uint64_t *sel_key,
                                                                  const uint32_t *sel_idx, uint64_t *tile_key,
                                                                  uint32_t *tile_idx, const double *obj)
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
             const bool up = (pos & size) == 0;
             const uint64_t ka = sk[pos], kb = sk[par];
             const uint32_t ia = si[pos], ib = si[par];
-            if (comp_less(kb, ib, ka, ia, obj) == up) {
+            if (comp_less<TIE>(kb, ib, ka, ia, obj) == up) {
                 sk[pos] = kb; sk[par] = ka;
                 si[pos] = ib; si[par] = ia;
             }
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
     }
 }
 
+template <bool TIE>
 __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
                                                                   const uint64_t *tile_key, const uint32_t *tile_idx,
                                                                   int64_t *idx_out, double *score_out, const double *obj)
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
         int lo = 0, hi = TK_TILE;
         while (lo < hi) {                                     // <= 10 steps
             const int mid = (lo + hi) >> 1;
-            const bool less = comp_less(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie, obj);
+            const bool less = comp_less<TIE>(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie, obj);
             lo = less ? mid + 1 : lo;
             hi = less ? hi : mid;
         }
@@ -492,10 +501,17 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;
     uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
     const double *tie_obj = (mode == TK_MODE_COMBALL) ? h->d_obj : nullptr;
-    hipLaunchKernelGGL(tk_tilesort_kernel, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key, h->d_sel_idx,
-                       tile_key, tile_idx, tie_obj);
-    hipLaunchKernelGGL(tk_mergerank_kernel, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                       h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
+    if (tie_obj) {
+        hipLaunchKernelGGL(tk_tilesort_kernel<true>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
+                           h->d_sel_idx, tile_key, tile_idx, tie_obj);
+        hipLaunchKernelGGL(tk_mergerank_kernel<true>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
+                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
+    } else {
+        hipLaunchKernelGGL(tk_tilesort_kernel<false>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
+                           h->d_sel_idx, tile_key, tile_idx, tie_obj);
+        hipLaunchKernelGGL(tk_mergerank_kernel<false>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
+                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
+    }
     HIP_TRY(h, hipGetLastError());
     if (d_counters_out) *d_counters_out = ws->counters;
     return 0;
