@@ -11,6 +11,12 @@
 #define TK_MAXBLK 256
 #define TK_MAXK 8192
 #define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
+// Replicas of the global histogram: same-address device-scope atomics are serialised at ~15-20 ns
+// each, so 256 workgroups flushing into ONE row cost ~5 us per pass; block b adds into replica
+// b % TK_HREP (32 adds per cell) and the resolving block sums the replicas.
+#ifndef TK_HREP
+#define TK_HREP 8
+#endif
 
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
@@ -23,7 +29,7 @@ struct TkState {
 };
 
 struct TopkWs {
-    uint32_t hist[8][256];   // [pass 0..7 = digit 7..0][bin]
+    uint32_t hist[8][TK_HREP][256];   // [pass 0..7 = digit 7..0][replica][bin]
     int64_t counters[5];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
                              // [4] != 0: tk_hist_rest_kernel gave up waiting, the selection is void
     TkState state[9];        // state[p]: after p digits
@@ -78,7 +84,12 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
         need = ld_i64(&ws->state[p].need);       // written by the previous launch, or by another block of this one
         prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
     }
-    suf[t] = ld_u32(&ws->hist[p][t]);
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < TK_HREP; ++r) acc += ld_u32(&ws->hist[p][r][t]);
+        suf[t] = acc;
+    }
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {     // suffix sums S[t] = sum_{b >= t} hist[b]
         const uint32_t v = (t + off < 256) ? suf[t + off] : 0u;
@@ -131,7 +142,7 @@ static __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t 
                                    bool publish = false)
 {
     __shared__ uint32_t ticket;
-    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][threadIdx.x], hist[threadIdx.x]);
+    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][blockIdx.x % TK_HREP][threadIdx.x], hist[threadIdx.x]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
