@@ -63,6 +63,10 @@ struct sdpcut_ctx {
     int64_t L = 0;
     double *d_Q = nullptr;      // [L]
     double *d_vars = nullptr;   // [L + n]
+    // set by sdpcut_shard_head_device around its selection: the sort's last kernel also writes the
+    // record header and the padding (topk.hip, tk_mergerank_kernel)
+    int64_t *shard_rec = nullptr;
+    int64_t shard_rec_count = 0, shard_rec_len = -1;
     bool have_point = false;
 
     int64_t N = 0, base = 0;

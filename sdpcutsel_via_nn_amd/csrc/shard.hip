@@ -3,8 +3,9 @@
 //
 //   sdpcut_shard_head_device   local head of the ranking -> one packed int64 record
 //                              [class size, nb_violated, nb_positive, k_eff, void, 0,0,0 | scores | ids]
-//                              (fp64 bit-cast; unused slots = (-inf, INT64_MAX)); the counters are
-//                              written by a kernel from device memory, the host never sees them here
+//                              (fp64 bit-cast; unused slots = (-inf, INT64_MAX)); header and padding are
+//                              written by the selection's last kernel from device memory, the host
+//                              never sees the counters here
 //   (caller)                   all_gather_into_tensor of the records (torch.distributed / RCCL)
 //   sdpcut_shard_finish_round  unpack -> replicated merge (score desc, id asc) -> eigen-cut rows of
 //                              the merged head that belong to THIS shard -> one D2H, one sync
@@ -22,24 +23,6 @@ __global__ void shard_fill_kernel(int64_t count, int64_t *rec)
     if (i < count) {
         rec[SHARD_HDR + i] = __double_as_longlong(-__builtin_huge_val());
         rec[SHARD_HDR + count + i] = 0x7fffffffffffffffLL;
-    }
-}
-
-// header of the record + padding of the slots behind the entries the selection wrote
-__global__ void shard_header_kernel(int64_t *rec, const int64_t *c4, int64_t n, int is_opt, int64_t count)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t written = c4[4] ? 0 : c4[3];
-    if (i < count && i >= written) {
-        rec[SHARD_HDR + i] = __double_as_longlong(-__builtin_huge_val());
-        rec[SHARD_HDR + count + i] = 0x7fffffffffffffffLL;
-    }
-    if (i >= 4 && i < SHARD_HDR) rec[i] = (i == 4) ? c4[4] : 0;   // [4] != 0: the selection gave up, record void
-    if (i == 0) {
-        rec[0] = is_opt ? n : c4[0];      // length of this shard's list (class size)
-        rec[1] = c4[1];                   // nb_violated
-        rec[2] = c4[2];                   // nb_positive
-        rec[3] = c4[3];                   // entries actually written
     }
 }
 
@@ -93,12 +76,16 @@ extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t coun
     int64_t *rec = (int64_t *)d_record;
     const int grid = (int)((count + 255) / 256);
     if (h->N > 0) {
+        // the selection's last kernel writes the header (counters straight from device memory) and the
+        // padding behind the entries it emits: no extra launch
         const int64_t *d_c4 = nullptr;
+        h->shard_rec = rec;
+        h->shard_rec_count = count;
+        h->shard_rec_len = strat == SDPCUT_STRAT_OPT ? h->N : -1;
         int rc = rank_fast_enqueue(h, strat, 0, count, rec + SHARD_HDR + count, (double *)(rec + SHARD_HDR), &d_c4);
+        h->shard_rec = nullptr;
         if (rc < 0) return rc;
         if (rc != 1) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: request not eligible for the select path");
-        hipLaunchKernelGGL(shard_header_kernel, dim3(grid), dim3(256), 0, h->stream, rec, d_c4, h->N,
-                           strat == SDPCUT_STRAT_OPT ? 1 : 0, count);
     } else {
         hipLaunchKernelGGL(shard_fill_kernel, dim3(grid), dim3(256), 0, h->stream, count, rec);   // empty shard
     }

@@ -324,11 +324,25 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
 template <bool TIE>
 __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
                                                                   const uint64_t *tile_key, const uint32_t *tile_idx,
-                                                                  int64_t *idx_out, double *score_out, const double *obj)
+                                                                  int64_t *idx_out, double *score_out, const double *obj,
+                                                                  int64_t *rec_hdr, int64_t rec_count, int64_t rec_len)
 {
     __shared__ uint64_t sk[TK_MAXK];
     __shared__ uint32_t si[TK_MAXK];
     const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
+    if (rec_hdr) {
+        // shard record (shard.hip): this launch also writes the 8-word header in front of the head
+        // and pads the slots behind the entries it emits with (-inf, INT64_MAX); rec_len >= 0 is the
+        // length of the shard's list when that is not the class size (optimality ranking)
+        const int64_t g = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+        const int64_t written = ws->counters[4] ? 0 : ws->counters[3];
+        if (g < rec_count && g >= written) {
+            score_out[g] = -__builtin_huge_val();
+            idx_out[g] = 0x7fffffffffffffffLL;
+        }
+        if (g < 8)
+            rec_hdr[g] = g == 0 ? (rec_len >= 0 ? rec_len : ws->counters[0]) : g <= 4 ? ws->counters[g] : 0;
+    }
     if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
     const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
     for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 8 * TK_THREADS) {      // 8 loads in flight per thread
@@ -505,12 +519,14 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
         hipLaunchKernelGGL(tk_tilesort_kernel<true>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
                            h->d_sel_idx, tile_key, tile_idx, tie_obj);
         hipLaunchKernelGGL(tk_mergerank_kernel<true>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
+                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj, h->shard_rec,
+                           h->shard_rec_count, h->shard_rec_len);
     } else {
         hipLaunchKernelGGL(tk_tilesort_kernel<false>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
                            h->d_sel_idx, tile_key, tile_idx, tie_obj);
         hipLaunchKernelGGL(tk_mergerank_kernel<false>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj);
+                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj, h->shard_rec,
+                           h->shard_rec_count, h->shard_rec_len);
     }
     HIP_TRY(h, hipGetLastError());
     if (d_counters_out) *d_counters_out = ws->counters;
