@@ -91,6 +91,10 @@ int sdpcut_synchronize(sdpcut_handle h);
 int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widths,
                        const double *params, int64_t n_params);
 
+/* The four trained MLPs of the reference (k = 2 .. max_k), compiled into the library from
+ * data/nn_weights.npz: sdpcut_set_network for each of them without the caller holding weights. */
+int sdpcut_set_builtin_networks(sdpcut_handle h, int max_k);
+
 /* Instance table: packed row-major upper triangle of the objective, length n(n+1)/2
  * (self._Q_arr, cut_select_qp.py:318-321 / cut_select_qcqp.py:247-256). */
 int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr);
@@ -103,6 +107,35 @@ int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr);
  */
 int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, int32_t ld,
                           const int32_t *ks, int64_t global_base);
+
+/*
+ * The C4 workload of SURVEY.md section 8 d, generated in device memory: N random k-variable index
+ * sets, candidate id -> set through a counter-based generator (Philox4x32-10 keyed by `seed`,
+ * counter = (id, attempt, block); k draws floor(u32 * nb_vars / 2^32), sorted, redrawn until
+ * distinct: every k-subset equally likely, ids independent of each other and of N).  The handle's
+ * list becomes the ids first_id .. first_id + N - 1, which are also the GLOBAL indices it reports
+ * (shard r of a multi-GPU run passes first_id = r * N).  Replaces, for synthetic batches, the
+ * host-built list of sdpcut_set_candidates; csrc/philox.h is the arithmetic, synthetic.py its
+ * numpy twin.  Needs nb_vars >= 2 k.
+ */
+int sdpcut_set_candidates_philox(sdpcut_handle h, int32_t k, int64_t N, uint64_t seed, int64_t first_id);
+
+/*
+ * Semidefinite vertex cover P^E_dim enumerated on the device, straight into the handle's candidate
+ * list (replaces _get_sdp_vertex_cover's index-set loops, cut_select_qp.py:399-524, AND the upload
+ * of their result): same sets, same order as sdpcut_enumerate_cover.  adjacency as there
+ * ([nb_vars][nb_vars] bytes, nb_vars of sdpcut_set_instance, <= 1024).  *count_out = number of
+ * candidates.  max_subs > 0 mirrors the reference's RAM guard (_THRES_MAX_SUBS, :117-120): with
+ * count >= max_subs only the count is returned and the handle's list is left alone; 0 = no guard.
+ */
+int sdpcut_set_candidates_cover(sdpcut_handle h, const uint8_t *adjacency, int32_t dim, int64_t max_subs,
+                                int64_t *count_out);
+
+/* Index sets of `count` candidates given by LOCAL index, device -> host: set_inds_out [count][5]
+ * padded with -1, ks_out [count] (0 for an index outside the list).  For lists that were generated
+ * or enumerated on the device: the host names only the few thousand selected candidates. */
+int sdpcut_get_candidates(sdpcut_handle h, int64_t count, const int64_t *idx, int32_t *set_inds_out,
+                          int32_t *ks_out);
 
 /* LP point vars_values = [X packed (L) | x (n)]  (cut_select_qp.py:137, 200, 547). */
 int sdpcut_set_point(sdpcut_handle h, const double *vars_values);
@@ -288,6 +321,27 @@ int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, do
 /* Self-test hook: multiplies A[16x4] * B[4x16] with v_mfma_f64_16x16x4_f64 using the
  * fragment maps the MLP kernel assumes; C row-major [16][16]. */
 int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C);
+
+/*
+ * The reference's own FFI, kept so that its binding works on this library unchanged:
+ *
+ *     nn_library = ctypes.cdll.LoadLibrary(<this library instead of 'neural_nets/NNs.so'>)   cut_select_qp.py:297
+ *     func_dim = getattr(nn_library, "neural_net_%dD" % d); func_dim.restype = c_double     :299-300
+ *     input_arr = (c_double * (d (d+3) / 2))();  ...  nn(input_arr)                          :302, :579-582
+ *     (also utilities.py:80-89, :157)
+ *
+ * X = [x_rho (d) | Q_slice (d(d+1)/2)], returns the raw network output.  One call = a batch of one
+ * on a process-wide default handle (device SDPCUT_COMPAT_DEVICE, default 0) with the built-in
+ * networks.  NNs_initialize / NNs_terminate (no-ops in NNs.so) create / destroy that handle; the
+ * first neural_net_kD call creates it if needed.  Without a gfx950 device the functions report
+ * once on stderr and return NaN -- there is no CPU fallback.
+ */
+double neural_net_2D(const double X[5]);
+double neural_net_3D(const double X[9]);
+double neural_net_4D(const double X[14]);
+double neural_net_5D(const double X[20]);
+void NNs_initialize(void);
+void NNs_terminate(void);
 
 #ifdef __cplusplus
 }

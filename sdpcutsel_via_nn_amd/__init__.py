@@ -5,7 +5,8 @@ hand-written gfx950 HIP kernels behind a C-ABI (include/sdpcut.h), with a host m
 the reference's ``CutSolver`` selection methods.
 """
 from ._capi import EIG, NN, Scorer, SdpCutError, load_library  # noqa: F401
-from .cut_solver import CutSolver, CutSolverQCQP, GpuCutSelectionMixin, RankList  # noqa: F401
+from .cut_solver import (CutSolver, CutSolverQCQP, GpuCutSelectionMixin, RankList,  # noqa: F401
+                         make_dropin_classes)
 
 __all__ = ["Scorer", "SdpCutError", "load_library", "EIG", "NN", "CutSolver", "CutSolverQCQP",
-           "GpuCutSelectionMixin", "RankList"]
+           "GpuCutSelectionMixin", "RankList", "make_dropin_classes"]

@@ -38,6 +38,10 @@ SIGNATURES = {
     "sdpcut_set_network": [_vp, _c.c_int, _c.c_int, _i32p, _dp, _c.c_int64],
     "sdpcut_set_instance": [_vp, _c.c_int32, _dp],
     "sdpcut_set_candidates": [_vp, _c.c_int64, _i32p, _c.c_int32, _i32p, _c.c_int64],
+    "sdpcut_set_candidates_philox": [_vp, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_int64],
+    "sdpcut_set_candidates_cover": [_vp, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i64p],
+    "sdpcut_get_candidates": [_vp, _c.c_int64, _i64p, _i32p, _i32p],
+    "sdpcut_set_builtin_networks": [_vp, _c.c_int],
     "sdpcut_set_point": [_vp, _dp],
     "sdpcut_set_point_device": [_vp, _vp],
     "sdpcut_score": [_vp, _c.c_uint32],
@@ -64,6 +68,8 @@ SIGNATURES = {
     "sdpcut_enumerate_cover": [_c.c_int32, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i32p, _i32p, _i64p],
 }
 _RESTYPES = {"sdpcut_last_error": _c.c_char_p}
+# the reference's own FFI (cut_select_qp.py:297-303), exported by the same library
+COMPAT_SYMBOLS = ["neural_net_2D", "neural_net_3D", "neural_net_4D", "neural_net_5D", "NNs_initialize", "NNs_terminate"]
 
 _lib = None
 
@@ -201,6 +207,39 @@ class Scorer(object):
         self.base = int(global_base)
         kmax = int(ks.max()) if ks.size else 2
         self.row_len = kmax * (kmax + 3) // 2
+
+    def set_builtin_networks(self, max_k=5):
+        """the reference's four trained MLPs, from the copy compiled into the library"""
+        self._check(self._lib.sdpcut_set_builtin_networks(self._h, int(max_k)))
+
+    def set_candidates_philox(self, k, count, seed=7, first_id=0):
+        """C4 workload: `count` random k-variable index sets generated on the device, candidate ids
+        first_id .. first_id + count - 1 (= the global indices reported)"""
+        self._check(self._lib.sdpcut_set_candidates_philox(self._h, int(k), int(count), int(seed), int(first_id)))
+        self.N, self.base = int(count), int(first_id)
+        self.row_len = int(k) * (int(k) + 3) // 2
+
+    def set_candidates_cover(self, adjacency, dim, max_subs=0):
+        """semidefinite vertex cover enumerated on the device into this handle's list
+        -> number of candidates (with max_subs > 0 and count >= max_subs the list is NOT replaced)"""
+        adj = np.ascontiguousarray(np.asarray(adjacency) != 0, dtype=np.uint8)
+        if adj.shape != (self.nb_vars, self.nb_vars):
+            raise ValueError("adjacency must be [n, n]")
+        cnt = _c.c_int64(0)
+        self._check(self._lib.sdpcut_set_candidates_cover(self._h, adj.ctypes.data_as(_c.POINTER(_c.c_uint8)), int(dim),
+                                                          int(max_subs or 0), ctypes.byref(cnt)))
+        if not (max_subs and cnt.value >= max_subs):
+            self.N, self.base = int(cnt.value), 0
+            self.row_len = int(dim) * (int(dim) + 3) // 2      # upper bound: the largest size present is <= dim
+        return int(cnt.value)
+
+    def get_candidates(self, local_idx):
+        """-> (set_inds int32 [count, 5] padded with -1, ks int32 [count]) of candidates by local index"""
+        idx = np.ascontiguousarray(local_idx, dtype=np.int64)
+        out = np.empty((max(idx.shape[0], 1), 5), dtype=np.int32)
+        ks = np.empty(max(idx.shape[0], 1), dtype=np.int32)
+        self._check(self._lib.sdpcut_get_candidates(self._h, idx.shape[0], _ptr(idx, _i64p), _ptr(out, _i32p), _ptr(ks, _i32p)))
+        return out[:idx.shape[0]], ks[:idx.shape[0]]
 
     def set_point(self, vars_values):
         vv = _f64(vars_values)

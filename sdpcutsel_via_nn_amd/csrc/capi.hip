@@ -44,9 +44,38 @@ int ensure_pinned(sdpcut_ctx *h, size_t bytes)
     return 0;
 }
 
+static void free_candidates(sdpcut_ctx *h);
+
+// Device arrays of a candidate list of N entries, cnt[k] of them with k variables (the callers
+// fill them: sdpcut_set_candidates from host arrays, the Philox generator and the cover
+// enumeration on the device).  Frees the previous list; sizes the ranking workspace.
+int alloc_candidates(sdpcut_ctx *h, int64_t N, const int64_t cnt[SDPCUT_MAX_K + 1], int64_t global_base)
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_candidates(h);
+    h->base = global_base;
+    const size_t nn = (size_t)(N < 1 ? 1 : N);
+    HIP_TRY(h, hipMalloc((void **)&h->d_set_orig, nn * 5 * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_k, nn * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_eig, nn * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_obj, nn * sizeof(double)));
+    h->row_len_max = 5;
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
+        Bucket &b = h->bucket[k];
+        b.n = cnt[k];
+        if (!cnt[k]) continue;
+        h->row_len_max = k * (k + 3) / 2;
+        HIP_TRY(h, hipMalloc((void **)&b.d_set, (size_t)cnt[k] * k * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&b.d_orig, (size_t)cnt[k] * sizeof(int32_t)));
+    }
+    h->N = N;
+    return ensure_rank_ws(h, N);
+}
+
 extern "C" {
 
-int sdpcut_version(void) { return 100; }
+int sdpcut_version(void) { return 200; }
 
 const char *sdpcut_last_error(sdpcut_handle h)
 {
@@ -85,6 +114,8 @@ int sdpcut_create(int device_id, sdpcut_handle *out)
     return SDPCUT_OK;
 }
 
+} // extern "C"
+
 static void free_candidates(sdpcut_ctx *h)
 {
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) {
@@ -96,6 +127,8 @@ static void free_candidates(sdpcut_ctx *h)
     h->d_set_orig = nullptr; h->d_k = nullptr; h->d_eig = nullptr; h->d_obj = nullptr;
     h->N = 0; h->scored = 0; h->last_total = -1;
 }
+
+extern "C" {
 
 int sdpcut_destroy(sdpcut_handle h)
 {
@@ -308,9 +341,6 @@ int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, i
     if (N < 0 || N > 0x7fffffffLL || (N > 0 && (!set_inds || !ks)) || ld < 2)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad candidate list");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    free_candidates(h);
-    h->base = global_base;
     // validate + bucket by size on the host (once per instance)
     int64_t cnt[SDPCUT_MAX_K + 1] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = 0; i < N; ++i) {
@@ -337,30 +367,18 @@ int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, i
             soa[k][(size_t)a * cnt[k] + p] = v;
         }
     }
-    const size_t nn = (size_t)(N < 1 ? 1 : N);
-    HIP_TRY(h, hipMalloc((void **)&h->d_set_orig, nn * 5 * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_k, nn * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_eig, nn * sizeof(double)));
-    HIP_TRY(h, hipMalloc((void **)&h->d_obj, nn * sizeof(double)));
+    int rc = alloc_candidates(h, N, cnt, global_base);
+    if (rc) return rc;
     if (N > 0) {
         HIP_TRY(h, hipMemcpy(h->d_set_orig, pad.data(), (size_t)N * 5 * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->d_k, kk.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
         Bucket &b = h->bucket[k];
-        b.n = cnt[k];
         if (!cnt[k]) continue;
-        HIP_TRY(h, hipMalloc((void **)&b.d_set, soa[k].size() * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc((void **)&b.d_orig, orig[k].size() * sizeof(int32_t)));
         HIP_TRY(h, hipMemcpy(b.d_set, soa[k].data(), soa[k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(b.d_orig, orig[k].data(), orig[k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    h->N = N;
-    h->row_len_max = 5;
-    for (int k = 2; k <= SDPCUT_MAX_K; ++k)
-        if (cnt[k]) h->row_len_max = k * (k + 3) / 2;
-    int rc = ensure_rank_ws(h, N);
-    if (rc) return rc;
     return SDPCUT_OK;
 }
 
@@ -389,6 +407,7 @@ int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
                               hipMemcpyDeviceToDevice, h->stream));
     h->have_point = true;
     h->scored = 0;
+    h->last_total = -1;
     return SDPCUT_OK;
 }
 

@@ -110,6 +110,8 @@ struct sdpcut_ctx {
 
 int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
 int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage
+// capi.hip: (re)allocate the device arrays of a list of N candidates, cnt[k] of them of size k
+int alloc_candidates(sdpcut_ctx *h, int64_t N, const int64_t cnt[SDPCUT_MAX_K + 1], int64_t global_base);
 int ensure_pinned(sdpcut_ctx *h, size_t bytes);  // capi.hip: grow h->pinned / h->pinned_dev
 
 #define HIP_TRY(h, expr)                                                                   \

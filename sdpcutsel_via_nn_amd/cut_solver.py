@@ -111,6 +111,38 @@ class RankList(Sequence):
         X_slice = tuple(self._vv[i] for i in Xarr_inds)
         return (idx, score, curr_pt, X_slice)
 
+    def _entries(self, lo, hi):
+        """Entry tuples of positions [lo, hi) built with array gathers (one fancy-indexing pass per
+        candidate size instead of a Python loop per value): what iteration and slicing use."""
+        hi = min(hi, self._n)
+        if hi <= lo:
+            return []
+        if hi - lo < 8:
+            return [self._entry(p) for p in range(lo, hi)]
+        b, vv, L, n = self._b, self._vv, self._b.nb_lifted, self._b.nb_vars
+        ids = np.asarray(self._idx[lo:hi], dtype=np.int64)
+        loc = ids - b.scorer.base
+        scores = np.asarray(self._score[lo:hi], dtype=np.float64).tolist()
+        S_all, ks = b.sets_of(loc)
+        out = [None] * (hi - lo)
+        for k in np.unique(ks):
+            k = int(k)
+            m = np.nonzero(ks == k)[0]
+            S = S_all[m, :k].astype(np.int64)
+            ia, ib = np.triu_indices(k)
+            pos = n * S[:, ia] - S[:, ia] * (S[:, ia] + 1) // 2 + S[:, ib]
+            if self._kind == 1:
+                for j, s_row, p_row in zip(m.tolist(), S.tolist(), pos.tolist()):
+                    i = int(ids[j])
+                    if b.agg_list is not None and not isinstance(b.agg_list, DeviceAgg):      # hand out the caller's own lists, as the reference does
+                        s_row, p_row = b.agg_list[int(loc[j])][0:2]
+                    out[j] = FeasEntry((s_row, scores[j], p_row, k), i, b)
+            else:
+                cp, Xs = vv[L + S].tolist(), vv[pos].tolist()
+                for t, j in enumerate(m.tolist()):
+                    out[j] = (int(ids[j]), scores[j], tuple(cp[t]), tuple(Xs[t]))
+        return out
+
     # -- Sequence protocol -----------------------------------------------------------
     def __len__(self):
         return self._n
@@ -118,8 +150,11 @@ class RankList(Sequence):
     def __getitem__(self, key):
         if isinstance(key, slice):
             rng = range(*key.indices(self._n))
-            if len(rng):
-                self._need(max(rng) + 1)
+            if not len(rng):
+                return []
+            self._need(max(rng) + 1)
+            if rng.step == 1:
+                return self._entries(rng.start, rng.stop)
             return [self._entry(p) for p in rng]
         if key < 0:
             key += self._n
@@ -130,15 +165,61 @@ class RankList(Sequence):
 
     def __iter__(self):
         for lo in range(0, self._n, 65536):
-            self._need(min(lo + 65536, self._n))
-            for p in range(lo, min(lo + 65536, self._n)):
-                yield self._entry(p)
+            hi = min(lo + 65536, self._n)
+            self._need(hi)
+            for e in self._entries(lo, hi):
+                yield e
 
     def __add__(self, other):
-        return list(self) + list(other)
+        """``a + b`` of cut_select_qcqp.py:79 without building either list: the caller slices
+        ``[0:sel_size]`` off the concatenation, and only that slice is materialised."""
+        return _Concat([self, other])
 
     def __radd__(self, other):
-        return list(other) + list(self)
+        return _Concat([other, self])
+
+
+class _Concat(Sequence):
+    """Lazy concatenation of rank lists (``rank_list_comb_obj + rank_list_feas_cons``)."""
+
+    def __init__(self, parts):
+        self._parts = [p for p in parts]
+
+    def __len__(self):
+        return sum(len(p) for p in self._parts)
+
+    def __iter__(self):
+        for p in self._parts:
+            for e in p:
+                yield e
+
+    def __getitem__(self, key):
+        n = len(self)
+        if isinstance(key, slice):
+            start, stop, step = key.indices(n)
+            if step != 1:
+                return [self[i] for i in range(start, stop, step)]
+            out, off = [], 0
+            for p in self._parts:
+                lo, hi = max(start - off, 0), min(stop - off, len(p))
+                if lo < hi:
+                    out.extend(p[lo:hi])
+                off += len(p)
+            return out
+        if key < 0:
+            key += n
+        off = 0
+        for p in self._parts:
+            if key - off < len(p):
+                return p[key - off]
+            off += len(p)
+        raise IndexError(key)
+
+    def __add__(self, other):
+        return _Concat(self._parts + [other])
+
+    def __radd__(self, other):
+        return _Concat([other] + self._parts)
 
 
 class _Binding(object):
@@ -148,19 +229,32 @@ class _Binding(object):
         self.scorer, self.agg_list = scorer, agg_list
         self.nb_vars, self.nb_lifted = nb_vars, nb_lifted
         self.rank_serial = 0
-        self.point_token = None
+        self.point_token = None  # identifies the LP point whose scores the device holds
+        self.point_obj = None    # the array it came from (kept alive: its id cannot be recycled)
+        self.point_vv = None
+        self.point_probe = None
+        self.point_round = None
         self.scored = 0
-        self.set_arr = None      # [N, 5] when bound from arrays
+        self.serial = 0
+        self.set_arr = None      # [N, 5] index sets as arrays (vectorised entry building)
 
     def agg_entry(self, idx):
         if self.agg_list is not None:
             e = self.agg_list[idx]
             return e[0], e[1]
-        k = int(self.ks[idx])
-        s = [int(v) for v in self.set_arr[idx, :k]]
+        S, ks = self.sets_of(np.array([idx], dtype=np.int64))
+        k = int(ks[0])
+        s = [int(v) for v in S[0, :k]]
         n = self.nb_vars
         pos = [n * s[a] - s[a] * (s[a] + 1) // 2 + s[b] for a in range(k) for b in range(a, k)]
         return s, pos
+
+    def sets_of(self, local_ids):
+        """(index sets [m, 5], sizes [m]) of candidates by local index: from the host arrays the
+        list was bound from, or fetched from the device for lists that only exist there."""
+        if self.set_arr is not None:
+            return self.set_arr[local_ids], self.ks[local_ids]
+        return self.scorer.get_candidates(local_ids)
 
 
 class AggArrays(Sequence):
@@ -172,9 +266,19 @@ class AggArrays(Sequence):
         self.set_inds = np.ascontiguousarray(set_inds, dtype=np.int32)
         self.ks = np.ascontiguousarray(ks, dtype=np.int32)
         self.nb_vars, self.Q_arr = nb_vars, Q_arr
+        self.serial = 0          # bumped by shuffle(): device bindings of the old order are stale
 
     def __len__(self):
         return self.ks.shape[0]
+
+    def shuffle(self):
+        """In-place random reordering, the array form of ``np.random.shuffle(agg_list)``
+        (cut_select_qp.py:636): ``np.random.permutation(N)`` draws the same permutation from the
+        global legacy generator as the list shuffle would (same seed -> same order)."""
+        perm = np.random.permutation(len(self))
+        self.set_inds = np.ascontiguousarray(self.set_inds[perm])
+        self.ks = np.ascontiguousarray(self.ks[perm])
+        self.serial += 1
 
     def __getitem__(self, idx):
         if isinstance(idx, slice):
@@ -189,6 +293,36 @@ class AggArrays(Sequence):
         max_elem = k * abs(max(q, key=abs))
         max_elem += 1 if not max_elem else 0
         return (s, pos, tuple(np.divide(q, max_elem)), max_elem)
+
+
+class DeviceAgg(Sequence):
+    """``agg_list`` whose index sets were enumerated on the device and never came to the host
+    (``sdpcut_set_candidates_cover``): a length, and records fetched on demand for the few entries
+    somebody indexes.  Bound to the scorer that holds the list."""
+
+    def __init__(self, scorer, count, nb_vars, Q_arr=None):
+        self.scorer, self._n, self.nb_vars, self.Q_arr = scorer, int(count), nb_vars, Q_arr
+        self.serial = 0
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            rng = range(*idx.indices(self._n))
+            S, ks = self.scorer.get_candidates(np.fromiter(rng, dtype=np.int64, count=len(rng)))
+            return [AggArrays(S[i:i + 1], ks[i:i + 1], self.nb_vars, self.Q_arr)[0] for i in range(len(rng))]
+        if idx < 0:
+            idx += self._n
+        if not 0 <= idx < self._n:
+            raise IndexError(idx)
+        S, ks = self.scorer.get_candidates(np.array([idx], dtype=np.int64))
+        return AggArrays(S, ks, self.nb_vars, self.Q_arr)[0]
+
+    def to_arrays(self):
+        """the whole list on the host (tests; the random strategy reorders a host copy)"""
+        S, ks = self.scorer.get_candidates(np.arange(self._n, dtype=np.int64))
+        return AggArrays(S, ks, self.nb_vars, self.Q_arr)
 
 
 class GpuCutSelectionMixin(object):
@@ -226,9 +360,14 @@ class GpuCutSelectionMixin(object):
         agg = self._agg_list
         key = id(agg)
         b = self._gpu_bindings.get(key)
-        if b is not None and b.agg_list is agg and b.n_at_bind == len(agg):
+        if b is not None and b.agg_list is agg and b.n_at_bind == len(agg) and b.serial == getattr(agg, "serial", 0):
             return b
         N = len(agg)
+        if isinstance(agg, DeviceAgg):          # the list already lives on its scorer
+            b = _Binding(agg.scorer, agg, self._nb_vars, self._nb_lifted)
+            b.n_at_bind, b.serial = N, agg.serial
+            self._gpu_bindings[key] = b
+            return b
         if isinstance(agg, AggArrays):          # enumerated on our side: the arrays already exist
             S, ks = agg.set_inds, agg.ks
         else:
@@ -243,7 +382,8 @@ class GpuCutSelectionMixin(object):
         sc.set_candidates(S[:N], ks[:N])
         b = _Binding(sc, agg, self._nb_vars, self._nb_lifted)
         b.n_at_bind = N
-        b.ks = ks[:N]
+        b.ks, b.set_arr = ks[:N], S[:N]
+        b.serial = getattr(agg, "serial", 0)
         self._gpu_bindings[key] = b
         return b
 
@@ -259,12 +399,26 @@ class GpuCutSelectionMixin(object):
         return b
 
     @staticmethod
-    def _gpu_point(b, vars_values, flags):
-        vv = np.ascontiguousarray(vars_values, dtype=np.float64)
-        token = (vv.ctypes.data, vv.shape[0], hash(vv.tobytes()))
-        if b.point_token != token:
+    def _gpu_point(b, vars_values, flags, cut_round=None):
+        """Make ``vars_values`` the device's LP point and score what ``flags`` asks for.
+
+        The upload is skipped only when the SAME array object (kept alive by the binding, so
+        its identity cannot be recycled) is presented again for the same round; a strided probe
+        of 64 entries guards against in-place edits of that object.  No hashing of the whole
+        point (4 MB at n = 1000) per call."""
+        vv = vars_values if (isinstance(vars_values, np.ndarray) and vars_values.dtype == np.float64 and
+                             vars_values.flags.c_contiguous) else np.ascontiguousarray(vars_values, dtype=np.float64)
+        step = max(1, vv.shape[0] // 64)
+        same = ((b.point_obj is vars_values or b.point_vv is vars_values) and (cut_round is None or b.point_round is None or cut_round == b.point_round)
+                and np.array_equal(vv[::step], b.point_probe))
+        if not same:
             b.scorer.set_point(vv)
-            b.point_token, b.scored = token, 0
+            b.point_serial = getattr(b, "point_serial", 0) + 1
+            b.point_token = b.point_serial
+            b.point_obj, b.point_vv, b.point_probe, b.scored = vars_values, vv, vv[::step].copy(), 0
+            b.point_round = cut_round
+        elif cut_round is not None and b.point_round is None:
+            b.point_round = cut_round
         need = flags & ~b.scored
         if need:
             b.scorer.score(need)
@@ -277,8 +431,16 @@ class GpuCutSelectionMixin(object):
         same returns as cut_select_qp.py:543-703.  Strategies 3 / -1 need an exact SDP
         solver per candidate and are out of scope."""
         if strat == 5:
-            np.random.shuffle(self._agg_list)      # in place, like :636
-            return self._agg_list
+            # random order, in place, like :634-637; the device twin of the old order is dropped
+            agg = self._agg_list
+            if isinstance(agg, DeviceAgg):
+                agg = self._agg_list = agg.to_arrays()
+            if isinstance(agg, AggArrays):
+                agg.shuffle()
+            else:
+                np.random.shuffle(agg)
+            getattr(self, "_gpu_bindings", {}).pop(id(agg), None)
+            return agg
         if strat not in (1, 2, 4):
             raise NotImplementedError("exact-SDP strategies (3, -1) are not part of the GPU path")
         b = self._gpu_bind()
@@ -287,7 +449,7 @@ class GpuCutSelectionMixin(object):
         flags = {1: _capi.EIG, 2: _capi.NN, 4: _capi.EIG | _capi.NN}[strat]
         if N == 0:
             return []       # strat 4 included: sel_size is clamped to 0 and the reference falls through
-        vv = self._gpu_point(b, vars_values, flags)
+        vv = self._gpu_point(b, vars_values, flags, cut_round)
         # head fetched eagerly: what the loop can consume (sel_size is only passed for strat 4;
         # for 1 / 2 the cap of :37 bounds it).  Heads <= 8192 take the device's top-k select path.
         head = min(N, sel_size if (strat == 4 and sel_size > 0) else _HEAD)
@@ -308,55 +470,66 @@ class GpuCutSelectionMixin(object):
         sel_size = min(sel_size, len(rank_list))
         opt_sel, feas_sel = strat in (2, 3, 4, -1), strat == 1
         pair = self._sparse_pair or _default_sparse_pair()
-        rows, rhs_out = [], []
-        if sel_size > 0:
-            b, idx, vv = None, None, vars_values
-            if isinstance(rank_list, RankList):
-                b, idx, vv = rank_list._b, rank_list.ids(sel_size), rank_list._vv
-                if opt_sel and strong_only:                       # :725-726
-                    stop = np.nonzero(rank_list.scores(sel_size) <= 0)[0]
-                    if stop.size:
-                        idx = idx[:stop[0]]
-            else:
-                entries = list(rank_list[0:sel_size])
-                if opt_sel:
-                    if strong_only:
-                        cut = next((p for p, e in enumerate(entries) if e[1] <= 0), len(entries))
-                        entries = entries[:cut]
-                    idx = np.array([e[0] for e in entries], dtype=np.int64)
-                    b = self._gpu_bind()
-                elif feas_sel and all(isinstance(e, FeasEntry) for e in entries):
-                    idx = np.array([e.agg_idx for e in entries], dtype=np.int64)
-                    b = self._find_binding_for(entries)
-                if b is None or idx is None:
-                    return self._gen_from_entries(entries, feas_sel, vars_values, pair)
+        if sel_size <= 0:
+            self._my_prob.linear_constraints.add(lin_expr=[], rhs=[], senses=[])
+            return 0
+        # (binding, candidate indices, point) groups in list order; most lists have one group
+        groups, vv = None, vars_values
+        if isinstance(rank_list, RankList):
+            idx, vv = rank_list.ids(sel_size), rank_list._vv
+            if opt_sel and strong_only:                       # :725-726
+                stop = np.nonzero(rank_list.scores(sel_size) <= 0)[0]
+                if stop.size:
+                    idx = idx[:stop[0]]
+            groups = [(rank_list._b, idx)]
+        elif strat == 5 and rank_list is self._agg_list:
+            # random selection (:729-732): the shuffled list itself, entries 0 .. sel_size-1
+            groups = [(self._gpu_bind(), np.arange(sel_size, dtype=np.int64))]
+        else:
+            entries = list(rank_list[0:sel_size])
+            if opt_sel:
+                if strong_only:
+                    cut = next((p for p, e in enumerate(entries) if e[1] <= 0), len(entries))
+                    entries = entries[:cut]
+                groups = [(self._gpu_bind(), np.array([e[0] for e in entries], dtype=np.int64))]
+            elif feas_sel and all(isinstance(e, FeasEntry) and e.binding is not None for e in entries):
+                # runs of entries of one candidate list (the QCQP feasibility round concatenates the
+                # lists of two covers, cut_select_qcqp.py:79)
+                groups = []
+                for e in entries:
+                    if groups and groups[-1][0] is e.binding:
+                        groups[-1][1].append(e.agg_idx)
+                    else:
+                        groups.append((e.binding, [e.agg_idx]))
+                groups = [(g, np.array(ix, dtype=np.int64)) for g, ix in groups]
+            if groups is None:
+                return self._gen_from_entries(entries, feas_sel, vars_values, pair)
+        if not opt_sel or vv is None:
+            vv = vars_values
+        parts = []
+        for g, idx in groups:
             if idx.size:
-                if not opt_sel or vv is None:
-                    vv = vars_values
-                self._gpu_point(b, vv, 0)
-                lam, coef, rhs, cols, ks = b.scorer.cut_rows(idx - b.scorer.base)
-                keep = np.nonzero(lam < _THRES_NEG_EIGVAL)[0]          # :743
-                store = self._my_prob.linear_constraints
-                if hasattr(store, "add_csr"):
-                    # batched assembly (SURVEY 8 f row 4): the padded device rows become one CSR
-                    # block with array operations, no Python object per cut
-                    indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
-                    store.add_csr(indptr, ind, val, rhs[keep], "G")
-                    return int(keep.size)
-                for c in keep:
-                    w = int(ks[c]) * (int(ks[c]) + 3) // 2
-                    rows.append(pair(ind=cols[c, :w].tolist(), val=coef[c, :w].tolist()))
-                    rhs_out.append(float(rhs[c]))
-        self._my_prob.linear_constraints.add(lin_expr=rows, rhs=rhs_out, senses=["G"] * len(rows))
+                self._gpu_point(g, vv, 0)
+                parts.append(g.scorer.cut_rows(idx - g.scorer.base))
+        if not parts:
+            self._my_prob.linear_constraints.add(lin_expr=[], rhs=[], senses=[])
+            return 0
+        lam, coef, rhs, cols, ks = (np.concatenate(a) for a in zip(*parts)) if len(parts) > 1 else parts[0]
+        keep = np.nonzero(lam < _THRES_NEG_EIGVAL)[0]          # :743
+        store = self._my_prob.linear_constraints
+        if hasattr(store, "add_csr"):
+            # batched assembly (SURVEY 8 f row 4): the padded device rows become one CSR block with
+            # array operations, no Python object per cut
+            indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
+            store.add_csr(indptr, ind, val, rhs[keep], "G")
+            return int(keep.size)
+        rows, rhs_out = [], []
+        for c in keep:
+            w = int(ks[c]) * (int(ks[c]) + 3) // 2
+            rows.append(pair(ind=cols[c, :w].tolist(), val=coef[c, :w].tolist()))
+            rhs_out.append(float(rhs[c]))
+        store.add(lin_expr=rows, rhs=rhs_out, senses=["G"] * len(rows))
         return len(rows)
-
-    def _find_binding_for(self, entries):
-        """Binding whose candidate list ALL the FeasEntry objects index, else None (the QCQP
-        feasibility-only round mixes entries of two lists, cut_select_qcqp.py:79)."""
-        b = entries[0].binding
-        if b is not None and all(e.binding is b for e in entries):
-            return b
-        return None
 
     def _gen_from_entries(self, entries, feas_sel, vars_values, pair):
         """Generic path for entries that do not carry a candidate index (random strategy, foreign
@@ -498,72 +671,61 @@ class CutSolver(GpuCutSelectionMixin):
                 CutSolver._SDP_CUTS_PER_ROUND_MAX)
         return max(s, minimum)
 
-    # ------------------------------------------------------------------ round harness (SURVEY 8 f row 2)
+    # ------------------------------------------------------------------ rounds without CPLEX (SURVEY 8 f row 2)
     _CONVERGENCE_TOL = 10 ** (-3)         # cut_select_qp.py:29
 
     def cut_select_algo(self, filename, dim, sel_size, strat=2, nb_rounds_cuts=20, term_on=False,
-                        triangle_on=False, strong_only=False):
-        """Algorithm 1 on a BoxQP ``.in`` file without CPLEX: the call sequence of
-        cut_select_qp.py:73-221 (parse -> vertex cover -> McCormick relaxation -> rounds of
-        [select, generate, re-solve]) with scipy's HiGHS as LP solver, our C++ cover
-        enumeration and the GPU-backed selection / triangle separation.  Dense cuts (strat 0),
-        exact-SDP strategies and chordal extensions are out of scope.
-        Returns the reference's default tuple
-        (bounds per round, total time, round times, separation times, nb cuts per round, [], nb candidates)."""
-        from timeit import default_timer as timer
+                        triangle_on=False, strong_only=False, max_subs=_THRES_MAX_SUBS):
+        """Cutting-plane rounds on a BoxQP ``.in`` file, same arguments and default return tuple as
+        the reference's entry point (cut_select_qp.py:73-221), with HiGHS as LP solver, the native
+        cover enumeration and the GPU selection / generation / triangle separation in between.
+        ``max_subs=None`` lifts the reference's 4e6 candidate guard (:117-120).  Dense cuts
+        (strat 0), exact-SDP strategies and chordal extensions are out of scope.
+        -> (bound per solve, total s, round s, separation s, PSD cuts per round, triangle cuts per
+        round, number of candidates)."""
+        from timeit import default_timer as clock
         from . import harness
-        assert strat in (1, 2, 4, 5), "strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random"
+        if strat not in (1, 2, 4, 5):
+            raise AssertionError("strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random")
         assert 0 < sel_size, "The selection size must be a % or number (of cuts) >0!"
         assert dim <= 5, "Keep SDP vertex cover low-dimensional (<=5)!"
-        time_begin = timer()
-        nbs_sdp_cuts, nbs_tri_cuts, curr_obj_vals, round_times, sep_times = [0], [], [], [], []
+        t_start = clock()
+        inst = harness.parse_boxqp(filename)
         self._dim = dim
+        self._nb_vars, self._nb_lifted, self._Q_arr, self._Q_adj = (inst[k] for k in ("nb_vars", "nb_lifted", "Q_arr", "adj"))
+        self._gpu_nets = {}
         if strat in (2, 4):
             self._load_neural_nets()
-        inst = harness.parse_boxqp(filename)
-        self._nb_vars, self._nb_lifted, self._Q_arr = inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
-        self._Q_adj = inst["adj"]
-        self._my_prob = my_prob = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
-        set_inds, ks, nb_subprobs = _capi.enumerate_cover(inst["adj"], dim, max_subs=self._THRES_MAX_SUBS)
-        if nb_subprobs >= self._THRES_MAX_SUBS or nb_rounds_cuts == 0:          # :117-120
-            return [0, 0], timer() - time_begin, 0, 0, [0], 0, nb_subprobs
-        self._agg_list = AggArrays(set_inds, ks, self._nb_vars, self._Q_arr)
-        sel_size_frac = sel_size
-        sel_size = self.selection_size(sel_size, nb_subprobs)
-        t0 = timer()
-        my_prob.linear_constraints.add(*harness.mccormick_rows(self._nb_vars, inst["adj"]))
-        sep_times.append(timer() - t0)
-        t0 = timer()
-        my_prob.solve()
-        round_times.append(timer() - t0 + sep_times[0])
-        curr_obj_vals.append(my_prob.get_objective_value())
-        vars_values = np.array(my_prob.get_values())
+        # the cover is enumerated on the device, straight into the scorer's candidate list
+        sc = self._gpu_new_scorer()
+        sc.set_instance(self._nb_vars, np.asarray(self._Q_arr, dtype=np.float64))
+        n_cand = sc.set_candidates_cover(inst["adj"], dim, max_subs=max_subs or 0)
+        if (max_subs and n_cand >= max_subs) or nb_rounds_cuts == 0:
+            sc.close()
+            return [0, 0], clock() - t_start, 0, 0, [0], 0, n_cand                      # the reference's guard tuple
+        self._agg_list = DeviceAgg(sc, n_cand, self._nb_vars, self._Q_arr)
+        quota = self.selection_size(sel_size, n_cand)
+        t_model = clock()
+        self._my_prob = lp = harness.boxqp_relaxation(inst)
+        t_model = clock() - t_model
         if triangle_on:
-            self._preprocess_triangle_ineq()                                       # :140-141
-        strat_change = strat
-        for cut_round in range(1, nb_rounds_cuts + 1):
-            if (term_on and len(curr_obj_vals) >= 3 and curr_obj_vals[-1] != curr_obj_vals[0] and
-                    (curr_obj_vals[-1] - curr_obj_vals[-2]) / (curr_obj_vals[-1] - curr_obj_vals[0])
-                    < self._CONVERGENCE_TOL):
-                break                                                              # :153-156
-            t_sep = timer()
-            if strat == 4:
-                res = self._sel_eigcut_by_ordering_on_measure(strat, vars_values, cut_round, sel_size=sel_size)
-                strat_change, rank_list = res if isinstance(res, tuple) else (strat, res)
-            else:
-                rank_list = self._sel_eigcut_by_ordering_on_measure(strat, vars_values, cut_round)
-            nbs_sdp_cuts.append(self._gen_eigcuts_selected(strat, sel_size, rank_list, strong_only=strong_only,
-                                                           vars_values=vars_values))
-            nbs_tri_cuts.append(self._separate_and_add_triangle(sel_size_frac, vars_values) if triangle_on else 0)
-            sep_times.append(timer() - t_sep)
-            strat = strat_change                                                   # :188
-            t0 = timer()
-            my_prob.solve()
-            round_times.append(timer() - t0 + sep_times[-1])
-            curr_obj_vals.append(my_prob.get_objective_value())
-            vars_values = np.array(my_prob.get_values()).astype(float)
-        return ([-obj for obj in curr_obj_vals], timer() - time_begin, round_times, sep_times, nbs_sdp_cuts,
-                nbs_tri_cuts, nb_subprobs)
+            self._preprocess_triangle_ineq()
+        state = {"strat": strat}
+
+        def separate(round_no, point):
+            cur = state["strat"]
+            picked = self._sel_eigcut_by_ordering_on_measure(cur, point, round_no, **({"sel_size": quota} if cur == 4 else {}))
+            if cur == 4 and isinstance(picked, tuple):
+                state["strat"], picked = picked       # the switch takes effect next round (:181 vs :188)
+            sdp = self._gen_eigcuts_selected(cur, quota, picked, strong_only=strong_only, vars_values=point)
+            tri = self._separate_and_add_triangle(sel_size, point) if triangle_on else 0
+            return {"sdp": sdp, "tri": tri}
+
+        log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts, setup_s=t_model,
+                                     stop_tol=self._CONVERGENCE_TOL if term_on else None)
+        sep = [t_model] + log.separation_s
+        return ([-v for v in log.bounds], clock() - t_start, [a + b for a, b in zip(log.solve_s, [0.0] + log.separation_s)],
+                sep, [0] + log.column("sdp"), log.column("tri"), n_cand)
 
 
 class CutSolverQCQP(CutSolver):
@@ -602,38 +764,55 @@ class CutSolverQCQP(CutSolver):
         return strat, rank_list, nb_a + nb_b, nb_opt_cuts
 
     def cut_select_algo(self, filename, dim, sel_size=0.1, strat=2, nb_rounds_cuts=20):
-        """Algorithm 1 adapted to QCQP on an OSiL file without CPLEX: the call sequence of
-        cut_select_qcqp.py:16-113 (parse -> McCormick on the objective's edges -> LP -> two
-        covers -> rounds) with HiGHS, our cover enumeration and the GPU-backed selection.
-        Returns (objective value per round, sel_size, nb cuts per round, nb optimality cuts per round)."""
+        """Cutting-plane rounds on a QCQP in OSiL format, same arguments and return tuple as the
+        reference's QCQP entry point (cut_select_qcqp.py:16-113), with HiGHS, the native enumeration
+        of both covers and :meth:`select_and_generate_round` between two solves.
+        -> (objective value per solve, sel_size, PSD cuts per round, optimality cuts per round)."""
         from . import harness
-        assert strat in (1, 2, 4, 5), "strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random"
+        if strat not in (1, 2, 4, 5):
+            raise AssertionError("strategies on the GPU path: 1 feasibility, 2 optimality, 4 combined, 5 random")
         assert 0 < sel_size, "The selection size must be a % or number (of cuts) >0!"
         assert dim <= 5, "Keep SDP vertex cover low-dimensional (<=5)!"
-        self._dim = dim
         inst = harness.parse_osil(filename)
+        self._dim = dim
         self._nb_vars, self._nb_lifted, self._Q_arr = inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
         self._Q_adj, self._Q_adj_cons = inst["adj"], inst["adj_cons"]
-        self._my_prob = my_prob = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
-        my_prob.linear_constraints.add(inst["rows"], inst["rhs"], inst["senses"])
-        my_prob.linear_constraints.add(*harness.mccormick_rows(self._nb_vars, inst["adj"]))      # :36
+        self._my_prob = lp = harness.LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
+        lp.linear_constraints.add(inst["rows"], inst["rhs"], inst["senses"])
+        lp.linear_constraints.add_csr(*harness.mccormick_csr(self._nb_vars, inst["adj"]), "L")
         self._load_neural_nets()
-        my_prob.solve()
-        obj_values_rounds = [my_prob.get_objective_value()]
-        vars_values = np.array(my_prob.get_values())
         (So, ko), (Sc, kc) = harness.qcqp_covers(inst, dim, _capi.enumerate_cover)               # :50, :314-334
-        agg_list = AggArrays(So, ko, self._nb_vars, self._Q_arr)
-        agg_list_cons = AggArrays(Sc, kc, self._nb_vars, self._Q_arr)
-        self._agg_list = agg_list
-        sel_size = self.selection_size(sel_size, len(agg_list), minimum=1)                       # :55-58
-        nbs_opt_cuts = [0] * (nb_rounds_cuts + 1)
-        nbs_sdp_cuts = [0]
-        for cut_round in range(1, nb_rounds_cuts + 1):
-            strat, rank_list, nb_sdp_cuts, nb_opt = self.select_and_generate_round(
-                strat, vars_values, cut_round, sel_size, agg_list, agg_list_cons)
-            nbs_opt_cuts[cut_round] = nb_opt
-            nbs_sdp_cuts.append(nb_sdp_cuts)
-            my_prob.solve()
-            obj_values_rounds.append(my_prob.get_objective_value())
-            vars_values = np.array(my_prob.get_values()).astype(float)
-        return obj_values_rounds, sel_size, nbs_sdp_cuts, nbs_opt_cuts
+        cover_obj = AggArrays(So, ko, self._nb_vars, self._Q_arr)
+        cover_cons = AggArrays(Sc, kc, self._nb_vars, self._Q_arr)
+        self._agg_list = cover_obj
+        quota = self.selection_size(sel_size, len(cover_obj), minimum=1)                         # :55-58
+        state = {"strat": strat}
+
+        def separate(round_no, point):
+            state["strat"], _, sdp, opt = self.select_and_generate_round(state["strat"], point, round_no, quota,
+                                                                         cover_obj, cover_cons)
+            return {"sdp": sdp, "opt": opt}
+
+        log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts)
+        opt = log.column("opt")
+        return log.bounds, quota, [0] + log.column("sdp"), [0] + opt + [0] * (nb_rounds_cuts - len(opt))
+
+
+def make_dropin_classes(cut_select_qp, cut_select_qcqp=None):
+    """Compose the GPU mixin with the reference's own classes (modules passed in, nothing is
+    imported here) -> (GpuCutSolver, GpuCutSolverQCQP or None).
+
+    The QCQP loop reaches the hot path through ``super()`` from inside ``CutSolverQCQP``
+    (cut_select_qcqp.py:41, :66-76), i.e. through whatever FOLLOWS ``CutSolverQCQP`` in the
+    instance's MRO.  Putting the mixin in front of ``CutSolverQCQP`` would leave those calls on
+    the reference's CPU loop; the mixin has to sit between the two reference classes:
+
+        GpuCutSolver     = (GpuCutSelectionMixin, CutSolver)
+        GpuCutSolverQCQP = (CutSolverQCQP, GpuCutSolver)
+        MRO: GpuCutSolverQCQP, CutSolverQCQP, GpuCutSolver, GpuCutSelectionMixin, CutSolver, object
+    """
+    qp = type("GpuCutSolver", (GpuCutSelectionMixin, cut_select_qp.CutSolver), {"__doc__": "CutSolver with the hot path on the GPU"})
+    qcqp = None
+    if cut_select_qcqp is not None:
+        qcqp = type("GpuCutSolverQCQP", (cut_select_qcqp.CutSolverQCQP, qp), {"__doc__": "CutSolverQCQP with the hot path on the GPU"})
+    return qp, qcqp

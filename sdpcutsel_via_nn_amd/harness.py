@@ -7,7 +7,7 @@ This module restates only the data side so that real instances can be driven end
 with scipy's HiGHS:
 
 * :func:`parse_boxqp`      -- ``.in`` file -> Q_arr / adjacency / linear term  (cut_select_qp.py:309-328)
-* :func:`mccormick_rows`   -- 2 diagonal + 3 off-diagonal RLT rows per edge   (cut_select_qp.py:352-375)
+* :func:`mccormick_csr`    -- the McCormick / RLT rows of cut_select_qp.py:352-375 as one CSR block
 * :class:`LinearRelaxation` -- row store with the ``linear_constraints.add(lin_expr=, rhs=, senses=)``
   surface that ``_gen_eigcuts_selected`` appends to (cut_select_qp.py:754), solved with HiGHS.
 
@@ -66,42 +66,93 @@ class _RowStore(object):
                            for r in range(len(ptr) - 1))
         return out
 
-    def csr_parts(self):
-        """(data, cols, lengths) of all rows in order, as arrays."""
+    def csr_parts(self, first_row=0):
+        """(data, cols, lengths) of the rows from ``first_row`` on, in order, as arrays."""
         data, cols, lens = [], [], []
+        seen = 0
         for b in self._blocks:
+            nb = len(b[1]) if b[0] == "rows" else len(b[1]) - 1
+            skip = min(max(first_row - seen, 0), nb)
+            seen += nb
+            if skip == nb:
+                continue
             if b[0] == "rows":
-                for row in b[1]:
+                for row in b[1][skip:]:
                     data.append(np.asarray(row.val, dtype=np.float64))
                     cols.append(np.asarray(row.ind, dtype=np.int64))
                     lens.append(len(row.ind))
             else:
                 _, ptr, ind, val = b
-                data.append(val)
-                cols.append(ind)
-                lens.extend(np.diff(ptr).tolist())
+                data.append(val[ptr[skip]:])
+                cols.append(ind[ptr[skip]:])
+                lens.extend(np.diff(ptr[skip:]).tolist())
         cat = (lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt))
         return cat(data, np.float64), cat(cols, np.int64), np.asarray(lens, dtype=np.int64)
 
 
 class LinearRelaxation(object):
     """Minimal LP model: min c^T v, 0 <= v <= 1, rows added through
-    ``self.linear_constraints.add`` exactly as the reference does on its CPLEX object."""
+    ``self.linear_constraints.add`` exactly as the reference does on its CPLEX object.
 
-    def __init__(self, obj_coeffs):
+    Solved with HiGHS' dual simplex.  When SciPy's bundled HiGHS binding is importable the model
+    is kept inside the solver between solves and only the rows added since the last solve are
+    passed on, so a round re-optimises from the previous basis (what the reference gets from
+    CPLEX, cut_select_qp.py:106-110, :194); otherwise every solve starts from scratch through
+    ``scipy.optimize.linprog``."""
+
+    def __init__(self, obj_coeffs, incremental=True):
         self.obj = np.asarray(obj_coeffs, dtype=np.float64)
         self.linear_constraints = _RowStore()
         self._values = None
         self._objval = None
+        self._core = None
+        if incremental:
+            try:
+                import scipy.optimize._highspy._core as core
+                self._core = core
+            except ImportError:
+                pass
+        self._model, self._rows_passed = None, 0
+
+    def _solve_incremental(self):
+        core, st, nv = self._core, self.linear_constraints, self.obj.shape[0]
+        if self._model is None:
+            m = core._Highs()
+            m.setOptionValue("output_flag", False)
+            m.setOptionValue("solver", "simplex")
+            m.setOptionValue("simplex_strategy", 1)          # dual simplex
+            m.setOptionValue("presolve", "off")              # keep the basis meaningful across rounds
+            m.addVars(nv, np.zeros(nv), np.ones(nv))
+            m.changeColsCost(nv, np.arange(nv, dtype=np.int32), self.obj)
+            self._model = m
+        m = self._model
+        data, cols, lens = st.csr_parts(self._rows_passed)
+        r = lens.shape[0]
+        if r:
+            senses = np.asarray(st.senses[self._rows_passed:])
+            rhs = np.asarray(st.rhs[self._rows_passed:], dtype=np.float64)
+            inf = core.kHighsInf
+            lower = np.where(senses == "L", -inf, rhs)
+            upper = np.where(senses == "G", inf, rhs)
+            starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+            m.addRows(r, lower, upper, int(data.shape[0]), starts, cols.astype(np.int32), data)
+            self._rows_passed += r
+        m.run()
+        if m.getModelStatus() != core.HighsModelStatus.kOptimal:
+            raise RuntimeError("HiGHS: " + m.modelStatusToString(m.getModelStatus()))
+        self._values = np.array(m.getSolution().col_value, dtype=np.float64)
+        self._objval = float(m.getInfo().objective_function_value)
 
     def solve(self):
+        st = self.linear_constraints
+        assert np.all(np.isin(np.asarray(st.senses), ["G", "L", "E"]))
+        if self._core is not None:
+            return self._solve_incremental()
         from scipy.optimize import linprog
         from scipy.sparse import csr_matrix
-        st = self.linear_constraints
         nv = self.obj.shape[0]
         data, cols, lens = st.csr_parts()
         senses = np.asarray(st.senses)
-        assert np.all(np.isin(senses, ["G", "L", "E"]))
         sign = np.where(senses == "G", -1.0, 1.0)
         rhs = np.asarray(st.rhs, dtype=np.float64) * sign
         ptr = np.concatenate([[0], np.cumsum(lens)])
@@ -138,31 +189,101 @@ def parse_boxqp(path):
     return dict(nb_vars=n, nb_lifted=n * (n + 1) // 2, c=c, Q_arr=Q_arr, adj=adj)
 
 
-def mccormick_rows(nb_vars, adj):
-    """RLT rows over variables [X packed | x] (cut_select_qp.py:352-375)."""
-    L = nb_vars * (nb_vars + 1) // 2
-    rows, rhs, senses = [], [], []
-    for i in range(nb_vars):
-        Xii, xi = nb_vars * i - i * (i - 1) // 2, L + i
-        rows += [SparsePair([Xii, xi], [1, -1]), SparsePair([Xii, xi], [-1, 2])]
-        rhs += [0, 1]
-        senses += ["L", "L"]
-        for j in range(i + 1, nb_vars):
-            if adj[i, j]:
-                Xij, xj = Xii + j - i, xi + j - i
-                rows += [SparsePair([Xij, xi, xj], [-1, 1, 1]),
-                         SparsePair([Xij, xi], [1, -1]),
-                         SparsePair([Xij, xj], [1, -1])]
-                rhs += [1, 0, 0]
-                senses += ["L", "L", "L"]
-    return rows, rhs, senses
+def mccormick_csr(nb_vars, adj):
+    """McCormick / RLT relaxation of X = x x^T on the edges of ``adj`` as ONE CSR block of "<="
+    rows over the variables [X packed | x] (what cut_select_qp.py:352-375 adds row by row):
+
+        per variable i:      X_ii - x_i <= 0,   -X_ii + 2 x_i <= 1
+        per edge i < j:     -X_ij + x_i + x_j <= 1,   X_ij - x_i <= 0,   X_ij - x_j <= 0
+
+    Rows are emitted variable by variable, a variable's two diagonal rows first and then its
+    edges by ascending j -- the reference's order, which the LP solver's vertex choice can depend
+    on.  -> (indptr, indices, values, rhs)."""
+    n = int(nb_vars)
+    L = n * (n + 1) // 2
+    A = np.asarray(adj) != 0
+    i_d = np.arange(n, dtype=np.int64)
+    X_d = n * i_d - i_d * (i_d - 1) // 2                      # packed position of X_ii
+    ei, ej = np.nonzero(np.triu(A, 1))
+    ei, ej = ei.astype(np.int64), ej.astype(np.int64)
+    X_e = X_d[ei] + (ej - ei)
+    # three slots per row, unused slot = -1; sort key = (variable, diagonal first, j, row kind)
+    W = 3 * n + 2
+    blocks = [
+        (i_d * W + 0, np.stack([X_d, L + i_d, -np.ones(n, np.int64)], 1), np.tile([1.0, -1.0, 0.0], (n, 1)), 0.0),
+        (i_d * W + 1, np.stack([X_d, L + i_d, -np.ones(n, np.int64)], 1), np.tile([-1.0, 2.0, 0.0], (n, 1)), 1.0),
+        (ei * W + 2 + 3 * ej + 0, np.stack([X_e, L + ei, L + ej], 1), np.tile([-1.0, 1.0, 1.0], (ei.size, 1)), 1.0),
+        (ei * W + 2 + 3 * ej + 1, np.stack([X_e, L + ei, -np.ones(ei.size, np.int64)], 1),
+         np.tile([1.0, -1.0, 0.0], (ei.size, 1)), 0.0),
+        (ei * W + 2 + 3 * ej + 2, np.stack([X_e, L + ej, -np.ones(ei.size, np.int64)], 1),
+         np.tile([1.0, -1.0, 0.0], (ei.size, 1)), 0.0),
+    ]
+    key = np.concatenate([b[0] for b in blocks])
+    cols = np.concatenate([b[1] for b in blocks])
+    vals = np.concatenate([b[2] for b in blocks])
+    rhs = np.concatenate([np.full(b[0].shape[0], b[3]) for b in blocks])
+    order = np.argsort(key, kind="stable")
+    cols, vals, rhs = cols[order], vals[order], rhs[order]
+    live = cols >= 0
+    indptr = np.concatenate([[0], np.cumsum(live.sum(axis=1))]).astype(np.int64)
+    return indptr, cols[live], vals[live], rhs
 
 
 def boxqp_relaxation(inst):
     """McCormick relaxation M of a parsed BoxQP instance, ready to solve."""
     lp = LinearRelaxation(np.concatenate([inst["Q_arr"], inst["c"]]))
-    lp.linear_constraints.add(*mccormick_rows(inst["nb_vars"], inst["adj"]))
+    lp.linear_constraints.add_csr(*mccormick_csr(inst["nb_vars"], inst["adj"]), "L")
     return lp
+
+
+# ---------------------------------------------------------------------------------------------
+# Cutting-plane rounds around the GPU path: "solve, separate, solve, ..." with timers.
+class RoundLog(object):
+    """What a run of cutting-plane rounds records: the LP bound after every solve (entry 0 = the
+    McCormick relaxation), and per round the separation time (selection + generation of cuts, the
+    reference's published "separation time"), the LP solve time and the cut counts reported by the
+    separator."""
+
+    def __init__(self):
+        self.bounds, self.solve_s, self.separation_s = [], [], []
+        self.counts = []            # one dict per round, as returned by the separator
+
+    def column(self, name, default=0):
+        return [c.get(name, default) for c in self.counts]
+
+    def stalled(self, tol):
+        """True when the last round closed less than ``tol`` of the gap closed so far (the
+        reference's optional stopping rule, cut_select_qp.py:153-156)."""
+        b = self.bounds
+        return len(b) >= 3 and b[-1] != b[0] and (b[-1] - b[-2]) / (b[-1] - b[0]) < tol
+
+
+def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=None):
+    """Drive ``max_rounds`` rounds on ``lp`` (anything with solve / get_values /
+    get_objective_value): ``separate(round_no, point) -> dict of counts`` appends cuts to the LP
+    between two solves.  ``setup_s`` is added to the first solve's time (model building).
+    -> RoundLog."""
+    from timeit import default_timer
+    clock = clock or default_timer
+    log = RoundLog()
+
+    def solve():
+        t = clock()
+        lp.solve()
+        log.solve_s.append(clock() - t)
+        log.bounds.append(lp.get_objective_value())
+        return np.asarray(lp.get_values(), dtype=np.float64)
+
+    point = solve()
+    log.solve_s[0] += setup_s
+    for round_no in range(1, max_rounds + 1):
+        if stop_tol is not None and log.stalled(stop_tol):
+            break
+        t = clock()
+        log.counts.append(separate(round_no, point))
+        log.separation_s.append(clock() - t)
+        point = solve()
+    return log
 
 
 def random_mccormick_point(nb_vars, rng):
@@ -250,9 +371,18 @@ def parse_osil(path):
 def qcqp_covers(inst, dim, enumerate_cover):
     """Objective / constraint covers of cut_select_qcqp.py:314-334: the sub-problems of the
     objective+constraints graph that also belong to the objective-only cover, and the rest
-    (both in the order of the objective+constraints enumeration).  -> two (set_inds, ks) pairs."""
+    (both in the order of the objective+constraints enumeration).  -> two (set_inds, ks) pairs.
+    The reference's O(N^2) list-membership tests become one sorted lookup over integer codes of
+    the index sets (base nb_vars + 1, padding = 0)."""
     So, ko, _ = enumerate_cover(inst["adj"], dim)
     Sc, kc, _ = enumerate_cover(inst["adj_cons"], dim)
-    in_obj = {tuple(int(v) for v in So[i, :ko[i]]) for i in range(ko.shape[0])}
-    mask = np.array([tuple(int(v) for v in Sc[i, :kc[i]]) in in_obj for i in range(kc.shape[0])], dtype=bool)
+    base = np.int64(inst["nb_vars"] + 1)
+
+    def codes(S):
+        c = np.zeros(S.shape[0], dtype=np.int64)
+        for a in range(5):
+            c = c * base + (S[:, a].astype(np.int64) + 1)      # -1 padding -> digit 0
+        return c
+
+    mask = np.isin(codes(Sc), codes(So))
     return (Sc[mask], kc[mask]), (Sc[~mask], kc[~mask])

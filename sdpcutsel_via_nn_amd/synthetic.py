@@ -42,3 +42,57 @@ def make_workload(nb_vars=100, k=3, count=10 ** 6, seed=7):
     pad[:, :k] = s
     return dict(nb_vars=nb_vars, Q_arr=Q_arr, vars_values=vars_values, set_inds=pad,
                 ks=np.full(count, k, dtype=np.int32))
+
+
+# ---------------------------------------------------------------------------------------------
+# C4 workload (SURVEY.md section 8 d): candidate id -> index set through Philox4x32-10.  The device
+# generates the list itself (sdpcut_set_candidates_philox, csrc/philox.h); this is the numpy twin
+# of the same arithmetic, used to verify sub-samples and to hand index sets to host-side checks.
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+PHILOX_MAX_ATTEMPTS = 64
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10: counters c0..c3 (uint32 arrays), key (k0, k1) scalars -> four uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & _MASK32 for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = _PHILOX_M0 * c0, _PHILOX_M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        c0, c1, c2, c3 = n0, p1 & _MASK32, n2, p0 & _MASK32
+        k0, k1 = (k0 + _PHILOX_W0) & 0xFFFFFFFF, (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def philox_index_sets(nb_vars, k, ids, seed=7):
+    """Index sets of the candidates ``ids`` (any int64 array) -> int32 [len(ids), 5] padded with -1:
+    k draws floor(u32 * nb_vars / 2^32), sorted, redrawn (attempt counter) until distinct."""
+    ids = np.asarray(ids, dtype=np.uint64).ravel()
+    out = np.full((ids.shape[0], 5), -1, dtype=np.int32)
+    todo = np.arange(ids.shape[0])
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for attempt in range(PHILOX_MAX_ATTEMPTS):
+        if not todo.size:
+            break
+        lo, hi = ids[todo] & _MASK32, ids[todo] >> np.uint64(32)
+        a = np.full(todo.shape[0], attempt, dtype=np.uint64)
+        r = list(philox4x32_10(lo, hi, a, np.zeros_like(a), k0, k1))
+        if k > 4:
+            r += list(philox4x32_10(lo, hi, a, np.ones_like(a), k0, k1))
+        v = np.stack([(x.astype(np.uint64) * np.uint64(nb_vars)) >> np.uint64(32) for x in r[:k]], axis=1).astype(np.int32)
+        v.sort(axis=1)
+        ok = np.all(v[:, 1:] != v[:, :-1], axis=1)
+        out[todo[ok], :k] = v[ok]
+        todo = todo[~ok]
+    out[todo, :k] = np.arange(k, dtype=np.int32)
+    return out
+
+
+def make_philox_workload(nb_vars=1000, k=3, seed=7):
+    """Instance part of the C4 workload (objective table and LP point as in :func:`make_instance`);
+    the index sets live on the device -> dict(nb_vars, Q_arr, vars_values, k, seed)."""
+    Q_arr, vars_values, _ = make_instance(nb_vars, seed)
+    return dict(nb_vars=nb_vars, Q_arr=Q_arr, vars_values=vars_values, k=k, seed=seed)

@@ -159,7 +159,7 @@ def run_instance(cs, tag, agg_list, nb_vars, Q_arr, points, sel_size, out):
 
 def mccormick_optimum(nb_vars, adj, Q_arr, c):
     lp = harness.LinearRelaxation(np.concatenate([Q_arr, c]))
-    lp.linear_constraints.add(*harness.mccormick_rows(nb_vars, adj))
+    lp.linear_constraints.add_csr(*harness.mccormick_csr(nb_vars, adj), "L")
     lp.solve()
     return np.asarray(lp.get_values())
 

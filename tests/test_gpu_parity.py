@@ -144,21 +144,13 @@ def assert_same_ranking(ids, ref_ids, ref_scores_by_id, exact):
     assert np.all(np.abs(a - b) <= 1e-9 * np.maximum(1.0, np.abs(b)))
 
 
-@pytest.mark.parametrize("tag", BOXQP_TAGS)
-@pytest.mark.parametrize("point", ["rnd", "mck", "psd"])
-def test_rankings_match_reference_goldens(scorer, oracle, golden_boxqp, tag, point):
-    """Scores, rank order, returned strategy and counters vs the rank lists captured from the
-    reference itself (mixed 2..5-variable candidate lists included)."""
-    from sdpcutsel_via_nn_amd import _capi
-    g = golden_boxqp
-    n = _bind_golden(scorer, g, tag, point)
+def _reference_scores(oracle, g, tag, point):
+    """per-candidate reference values at a golden point, from the oracle (pinned bit-exactly to the
+    reference's own lists by tests/test_oracle.py): obj_improve, lambda_min, max_elem"""
+    n = int(g[tag + "_nb_vars"])
     L = n * (n + 1) // 2
-    N = g[tag + "_set_inds"].shape[0]
-    sel = int(g[tag + "_sel_size"])
-    scorer.score(_capi.EIG | _capi.NN)
-    eig, obj = scorer.get_scores()
-    # reference per-candidate values from the oracle (itself pinned bit-exactly to the goldens)
     S, ks, vv = g[tag + "_set_inds"], g[tag + "_k"], g["%s_%s_vars" % (tag, point)]
+    N = S.shape[0]
     ref_obj, ref_eig, me = np.zeros(N), np.zeros(N), np.zeros(N)
     for k in np.unique(ks):
         m = np.nonzero(ks == k)[0]
@@ -166,27 +158,133 @@ def test_rankings_match_reference_goldens(scorer, oracle, golden_boxqp, tag, poi
         ref_obj[m] = oracle.opt_score_batch(int(k), si, n, vv, g[tag + "_Q_arr"])
         ref_eig[m] = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][oracle.triu_positions(si, n)])
         me[m] = max_elem_of(oracle, S[m], int(k), n, g[tag + "_Q_arr"])
+    return ref_obj, ref_eig, me
+
+
+@pytest.mark.parametrize("tag", BOXQP_TAGS)
+def test_rankings_match_reference_goldens_generic_point(scorer, oracle, golden_boxqp, tag):
+    """Scores, rank order, returned strategy and counters vs the rank lists captured from the
+    reference itself (mixed 2..5-variable candidate lists included) at a generic LP point:
+    bit-identical id sequences."""
+    from sdpcutsel_via_nn_amd import _capi
+    g, point = golden_boxqp, "rnd"
+    _bind_golden(scorer, g, tag, point)
+    N = g[tag + "_set_inds"].shape[0]
+    sel = int(g[tag + "_sel_size"])
+    scorer.score(_capi.EIG | _capi.NN)
+    eig, obj = scorer.get_scores()
+    ref_obj, ref_eig, me = _reference_scores(oracle, g, tag, point)
     assert np.abs(eig - ref_eig).max() <= EIG_ATOL
     assert obj_close(obj, ref_obj, me)
-    exact = point == "rnd"
     for strat in (1, 2, 4):
         q = "%s_%s_s%d" % (tag, point, strat)
         ids, score, total, new_strat, cnt = scorer.rank(strat, sel)
         ref_ids, ref_score = g[q + "_order"], g[q + "_score"]
-        if strat == 1 and not exact:
-            # violated-set membership of numerically singular matrices is rounding noise
-            viol_ref = set(ref_ids.tolist())
-            sym = set(ids.tolist()) ^ viol_ref
-            assert all(abs(ref_eig[i]) <= 1e-12 for i in sym)
-            continue
         assert total == ref_ids.shape[0]
+        assert np.array_equal(ids, ref_ids)                              # the whole list, not only its head
         by_id = np.zeros(N)
         by_id[ref_ids] = ref_score
-        assert_same_ranking(ids, ref_ids, by_id, exact)
         assert np.all(np.abs(score - by_id[ids]) <= OBJ_RTOL * np.maximum(np.abs(by_id[ids]), 1e-3 * me[ids]) + EIG_ATOL)
-        if exact:
-            assert new_strat == int(g[q + "_new_strat"])
-            assert np.array_equal(ids[:sel], ref_ids[:sel])          # bit-identical top-k selection
+        assert new_strat == int(g[q + "_new_strat"])
+        assert np.array_equal(ids[:sel], ref_ids[:sel])                  # bit-identical top-k selection
+
+
+TIE_RTOL = 1e-9        # reference scores closer than this (relative to max(1, |score|)) count as one tie group
+SINGULAR_ATOL = 1e-12  # |lambda_min| below this: whether the reference calls the matrix violated is LAPACK noise
+
+
+@pytest.mark.parametrize("tag", BOXQP_TAGS)
+@pytest.mark.parametrize("point", ["mck", "psd"])
+def test_rankings_match_reference_goldens_structured_points(scorer, oracle, golden_boxqp, tag, point):
+    """Structured LP vertices (round 1 of every BoxQP instance: x = 0.5, X in {0, 0.5}; and an all-PSD
+    point): thousands of candidates carry mathematically EQUAL scores and exactly singular matrices,
+    so the reference's order inside a group of equal scores -- and whether lambda_min = 0 +- 1e-16
+    counts as violated -- is rounding noise of its LAPACK / libm.  Checked here, for all three
+    strategies, order included:
+
+      1. index work is bit-exact at these points too: the device's list == the oracle's ranking
+         (stable sorts, combined scan, strategy switch) of the device's own scores;
+      2. against the list the reference produced: position by position the reference score of OUR
+         candidate equals the reference score of ITS candidate (TIE_RTOL) -- the lists are equal up to
+         permutations inside tie groups; lengths differ by at most the number of numerically singular
+         matrices, and the strategy switch agrees;
+      3. the top-`sel` SELECTION: every candidate we select and the reference does not (and vice
+         versa) is counted, and must belong to the tie group that straddles position `sel` (its
+         reference score equals both the last selected and the first unselected score) -- i.e. the
+         reference itself could not have told the two apart.  The counts go to
+         gpurun_out/r02_structured_point_parity.txt (summarised in DESIGN.md section 2)."""
+    from sdpcutsel_via_nn_amd import _capi
+    g = golden_boxqp
+    _bind_golden(scorer, g, tag, point)
+    N = g[tag + "_set_inds"].shape[0]
+    sel = int(g[tag + "_sel_size"])
+    scorer.score(_capi.EIG | _capi.NN)
+    eig, obj = scorer.get_scores()
+    ref_obj, ref_eig, me = _reference_scores(oracle, g, tag, point)
+    assert np.abs(eig - ref_eig).max() <= EIG_ATOL
+    assert obj_close(obj, ref_obj, me)
+    n_singular = int((np.abs(ref_eig) <= SINGULAR_ATOL).sum())
+    lines = []
+    for strat in (1, 2, 4):
+        q = "%s_%s_s%d" % (tag, point, strat)
+        ids, score, total, new_strat, cnt = scorer.rank(strat, sel)
+        ref_ids, ref_score = g[q + "_order"], g[q + "_score"]
+        # 1. bit-exact index work given the device's scores
+        order, o_score, o_strat, o_cnt = oracle.rank_arrays(strat, obj, eig, sel)
+        assert np.array_equal(ids, order) and np.array_equal(score, o_score + 0.0) and new_strat == o_strat
+        # 2. the reference's list, up to permutations inside tie groups
+        if strat == 1:
+            by_id = np.where(ref_eig < 0, -ref_eig, 0.0)                  # defined for the unlisted candidates too
+            assert abs(total - ref_ids.shape[0]) <= n_singular
+            sym = set(ids.tolist()) ^ set(ref_ids.tolist())
+            assert all(abs(ref_eig[i]) <= SINGULAR_ATOL for i in sym)
+        else:
+            assert total == ref_ids.shape[0] == N
+            by_id = np.zeros(N)
+            by_id[ref_ids] = ref_score
+        m = min(ids.shape[0], ref_ids.shape[0])
+        b = by_id[ref_ids[:m]]
+        if strat == 4:
+            # a candidate's combined score depends on whether the scan (cut_select_qp.py:606-623) reached it,
+            # and inside the tie group at the scan's stopping point the two sides reach different members:
+            # compare the sorted score sequences (with 1. and the per-candidate agreement of obj_improve /
+            # lambda_min above this pins the order up to ties), and let `same_group` below know that an
+            # un-bumped member (obj) and a bumped one (obj + BIG_M) of one obj_improve group are tied
+            a = score[:m]
+            alt = ref_obj + 1000.0
+        else:
+            a = by_id[ids[:m]]
+            alt = by_id
+            assert np.all(np.abs(score[:m] - a) <= OBJ_RTOL * np.maximum(np.abs(a), 1e-3 * me[ids[:m]]) + EIG_ATOL + SINGULAR_ATOL)
+        assert np.all(np.abs(a - b) <= TIE_RTOL * np.maximum(1.0, np.abs(b)) + SINGULAR_ATOL), (strat, np.abs(a - b).max())
+        assert new_strat == int(g[q + "_new_strat"])
+        # 3. the selection itself
+        w = min(sel, m)
+        ours, theirs = ids[:w], ref_ids[:w]
+        pos_diff = int((ours != theirs).sum())
+        only_ours = np.setdiff1d(ours, theirs)
+        only_theirs = np.setdiff1d(theirs, ours)
+        assert only_ours.shape == only_theirs.shape
+        straddle = 0
+        if only_ours.size:
+            assert w < ref_ids.shape[0], "a selection that takes the whole list cannot differ as a set"
+            last_in, first_out = by_id[ref_ids[w - 1]], by_id[ref_ids[w]]
+            tol = TIE_RTOL * max(1.0, abs(last_in)) + SINGULAR_ATOL
+            same_group = (np.abs(by_id - last_in) <= tol) | (np.abs(alt - last_in) <= tol)
+            assert same_group[ref_ids[w]]                               # a tie group straddles position sel
+            for i in np.concatenate([only_ours, only_theirs]):
+                assert same_group[i], (strat, int(i), by_id[i], last_in)
+            straddle = int(same_group.sum())
+        n_groups = int((np.abs(np.diff(b[:w])) > TIE_RTOL * np.maximum(1.0, np.abs(b[:w][1:]))).sum()) + 1 if w else 0
+        lines.append("%s %s strategy %d: N=%d sel=%d list %d (reference %d), singular matrices %d, distinct score values "
+                     "in the head %d, positions with another id %d, ids selected by one side only %d (tie group at the "
+                     "cut: %d candidates)" % (tag, point, strat, N, w, total, ref_ids.shape[0], n_singular, n_groups,
+                                              pos_diff, int(only_ours.size), straddle))
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "r02_structured_point_parity.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
 
 
 # --------------------------------------------------------------------------- cut rows

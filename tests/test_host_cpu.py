@@ -105,9 +105,20 @@ def test_harness_boxqp_and_mccormick(tmp_path):
     assert inst["c"].tolist() == [-1, 2, -3]
     assert inst["Q_arr"].tolist() == [-1.0, 4.0, 0.0, -3.0, -5.0, 4.0]
     assert inst["adj"].tolist() == [[True, True, False], [True, True, True], [False, True, True]]
-    rows, rhs, senses = harness.mccormick_rows(3, inst["adj"])
-    assert len(rows) == 2 * 3 + 3 * 2 and set(senses) == {"L"}
-    assert rows[0].ind == [0, 6] and rows[0].val == [1, -1]         # X00 <= x0
+    ptr, ind, val, rhs = harness.mccormick_csr(3, inst["adj"])
+    assert len(ptr) - 1 == 2 * 3 + 3 * 2 == len(rhs)
+    assert ind[ptr[0]:ptr[1]].tolist() == [0, 6] and val[ptr[0]:ptr[1]].tolist() == [1, -1]         # X00 <= x0
+    # row by row against the textbook definition, in the reference's order (cut_select_qp.py:352-375)
+    want = []
+    for i in range(3):
+        Xii = 3 * i - i * (i - 1) // 2
+        want += [([Xii, 6 + i], [1, -1], 0), ([Xii, 6 + i], [-1, 2], 1)]
+        for j in range(i + 1, 3):
+            if inst["adj"][i, j]:
+                Xij = Xii + j - i
+                want += [([Xij, 6 + i, 6 + j], [-1, 1, 1], 1), ([Xij, 6 + i], [1, -1], 0), ([Xij, 6 + j], [1, -1], 0)]
+    got = [(ind[ptr[r]:ptr[r + 1]].tolist(), val[ptr[r]:ptr[r + 1]].tolist(), rhs[r]) for r in range(len(rhs))]
+    assert got == want
     lp = harness.boxqp_relaxation(inst)
     lp.solve()
     v = np.asarray(lp.get_values())
