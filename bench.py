@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the cut-scoring hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c4-shard]
 
-One "step" = one selection round over one batch of synthetic candidates, inputs resident in
-HBM: copy the LP point device->device, score every candidate (Jacobi lambda_min + MLP
-optimality measure), rank with the combined strategy (sel_size = 5000), merge the per-shard
-heads (N > 1: RCCL all-gather), and generate the eigen-cut rows of the selected candidates.
-Workload at every N: BASELINE.json configs[1] per GPU (n = 100 dense, 1e6 random 3-variable
-index sets, seed 7 + rank) -> weak scaling; `value` = candidates scored per second over all
-ranks.  Rank 0 prints ONE JSON line.
+One "step" = one selection round over one batch of synthetic candidates whose index sets are
+resident in HBM, bracketed HOST TO HOST (SURVEY.md section 8 d): the LP point starts in a host
+array (`sdpcut_set_point`), every candidate is scored (Jacobi lambda_min + MLP optimality
+measure), ranked with the combined strategy (sel_size = 5000), the per-shard heads are merged
+(N > 1: one RCCL all-gather), the eigen-cut rows of the selected candidates are generated, and
+the round's results are back in host memory when the step ends.
+
+  c2 (default)  BASELINE.json configs[1] per GPU: n = 100 dense, 1e6 random 3-variable index sets
+                (seed 7 + rank), weak scaling -- the configuration the metric is quoted on;
+                at N = 1 the line also carries the k = 2, 4, 5 rates as secondary fields.
+  c4            BASELINE.json configs[3]: n = 1000, 1e8 3-variable candidates IN TOTAL, generated on
+                the device by the counter-based Philox generator (candidate id -> index set), rank r
+                takes ids [r, r+1) * 1e8 / N: strong scaling.
+  c4-shard      one rank's share of the 8-GPU form of c4 (1.25e7 candidates per GPU).
+
+`value` = candidates scored per second over all ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,9 +31,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PER_GPU = 10 ** 6
-NB_VARS = 100
-K = 3
 SEL = 5000
 BASELINE_METRIC = "candidate cuts scored/sec (eig+NN), 1e6 3-var subs, 1/2/4/8 GPU"    # BASELINE.json "metric"
 PREWARM_STEPS = 150    # untimed setup before the W warmup steps (GPU clock ramp), see main()
@@ -32,37 +38,88 @@ FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only
 BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
 HBM_PEAK_GBS = 8000.0
+KERNEL_NAMES = {2: "score_mfma_kernel<2, 64, 3, false>", 3: "score_mfma_kernel<3, 50, 3, false>",
+                4: "score_mfma_kernel<4, 50, 3, false>", 5: "score_mfma_kernel<5, 64, 4, false>"}
+CONFIGS = {
+    "c2": dict(nb_vars=100, k=3, total=None, per_gpu=10 ** 6, scaling="weak",
+               text="configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, eig + neural_net_3D "
+                    "scoring, combined ranking sel_size=5000, cut rows; host-to-host round"),
+    "c4": dict(nb_vars=1000, k=3, total=10 ** 8, per_gpu=None, scaling="strong",
+               text="configs[3]: synthetic n=1000, 1e8 3-var candidates in total from the on-device Philox generator, "
+                    "sharded by candidate id, RCCL all-gather of per-shard top-k; host-to-host round"),
+    "c4-shard": dict(nb_vars=1000, k=3, total=None, per_gpu=12_500_000, scaling="weak",
+                     text="configs[3], one of 8 shards: synthetic n=1000, 1.25e7 3-var candidates per GPU from the "
+                          "on-device Philox generator; host-to-host round"),
+}
 
 
-def cpu_baseline(wl, sample):
-    """The oracle ("port": C restatement of NNs.so + batched LAPACK eigvalsh + numpy ranking),
-    1 core, on the first `sample` candidates of the same workload."""
+# ----------------------------------------------------------------------------- CPU baseline (oracle = checker code, timed)
+def _cpu_score_chunk(args):
+    """worker of the all-cores leg: both measures for one chunk of candidates (oracle code)"""
+    k, nb_vars, si, vv, Q = args
     from oracle import cutsel_oracle as oracle
-    si = np.ascontiguousarray(wl["set_inds"][:sample, :K])
-    vv, Q = wl["vars_values"], wl["Q_arr"]
-    L = NB_VARS * (NB_VARS + 1) // 2
+    L = nb_vars * (nb_vars + 1) // 2
+    obj = oracle.opt_score_batch(k, si, nb_vars, vv, Q)
+    lam = oracle.eigmin_batch(k, vv[L:][si], vv[:L][oracle.triu_positions(si, nb_vars)])
+    return obj, lam
+
+
+def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
+    """The oracle ("port": C restatement of NNs.so + batched LAPACK eigvalsh + numpy ranking) on the
+    first `sample` candidates of the same workload: 1 core, all cores (process pool), and the
+    reference's own shape (per-candidate Python loop)."""
+    from oracle import cutsel_oracle as oracle
+    si = np.ascontiguousarray(set_inds[:sample, :k])
+    L = nb_vars * (nb_vars + 1) // 2
+    sel = min(SEL, sample)
+
+    def finish(obj, lam):
+        order, _, _, _ = oracle.rank_arrays(4, obj, lam, sel)
+        for c in order[:sel]:
+            oracle.get_eigendecomp(k, vv[L:][si[c]], vv[:L][oracle.triu_positions(si[c], nb_vars)], True)
+
     t0 = time.perf_counter()
-    obj = oracle.opt_score_batch(K, si, NB_VARS, vv, Q)
-    lam = oracle.eigmin_batch(K, vv[L:][si], vv[:L][oracle.triu_positions(si, NB_VARS)])
-    order, _, _, _ = oracle.rank_arrays(4, obj, lam, min(SEL, sample))
-    for c in order[:min(SEL, sample)][:SEL]:
-        w, v = oracle.get_eigendecomp(K, vv[L:][si[c]], vv[:L][oracle.triu_positions(si[c], NB_VARS)], True)
+    finish(*_cpu_score_chunk((k, nb_vars, si, vv, Q)))
     dt = time.perf_counter() - t0
+    out = dict(value=sample / dt, unit="candidates/s", cores=1, kind="port",
+               sample="first %d of the %d candidates of this workload, same round (score eig+NN, combined "
+                      "ranking, %d eigh cut rows), %.1f s" % (sample, n_workload, sel, dt))
+    # all host cores of the box (BASELINE.md section 3 item 2): the scoring split over a process pool
+    cores = min(os.cpu_count() or 1, 16)
+    if cores > 1:
+        import multiprocessing as mp
+        chunks = np.array_split(np.arange(sample), cores * 4)
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_cpu_score_chunk, [(k, nb_vars, si[:64], vv, Q)] * cores)          # start the workers (untimed)
+            t1 = time.perf_counter()
+            parts = pool.map(_cpu_score_chunk, [(k, nb_vars, si[c], vv, Q) for c in chunks])
+            finish(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+            dt_all = time.perf_counter() - t1
+        out["all_cores"] = dict(value=sample / dt_all, unit="candidates/s", cores=cores,
+                                sample="same sample, scoring over a %d-process pool (os.cpu_count() = %d), ranking "
+                                       "and cut rows on one, %.1f s" % (cores, os.cpu_count(), dt_all))
     # BASELINE.md section 3, item 1: the reference's own shape -- a Python loop with one ctypes call
     # into the NNs.so-compatible entry point and one LAPACK eigvalsh per candidate -- on a small
     # sub-sample (optimality list + feasibility list = both measures for every candidate)
     m = min(20000, sample)
-    agg = oracle.build_agg_list([tuple(int(v) for v in s) for s in si[:m]], NB_VARS, Q)
+    agg = oracle.build_agg_list([tuple(int(v) for v in s) for s in si[:m]], nb_vars, Q)
     t1 = time.perf_counter()
     oracle.sel_eigcut_by_ordering_on_measure(agg, L, 2, vv)
     oracle.sel_eigcut_by_ordering_on_measure(agg, L, 1, vv)
     dt_loop = time.perf_counter() - t1
-    return dict(value=sample / dt, unit="candidates/s", cores=1, kind="port",
-                sample="first %d of the %d candidates of this workload, same round (score eig+NN, combined "
-                       "ranking, %d eigh cut rows), %.1f s" % (sample, N_PER_GPU, min(SEL, sample), dt),
-                reference_style_loop=dict(value=m / dt_loop, unit="candidates/s", cores=1,
-                                          sample="per-candidate Python loop (ctypes NN + eigvalsh each) on the "
-                                                 "first %d candidates, %.1f s" % (m, dt_loop)))
+    out["reference_style_loop"] = dict(value=m / dt_loop, unit="candidates/s", cores=1,
+                                       sample="per-candidate Python loop (ctypes NN + eigvalsh each) on the first %d "
+                                              "candidates, %.1f s" % (m, dt_loop))
+    return out
+
+
+def roofline(k, n_per_launch, kernel_ms, traffic):
+    tflops = FLOPS_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e12
+    gbs = BYTES_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+            "traffic": traffic, "kernel": KERNEL_NAMES[k], "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
+            "flops_per_candidate": FLOPS_PER_CAND[k], "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+            "bytes_per_candidate": BYTES_PER_CAND[k]}
 
 
 def main():
@@ -70,11 +127,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the k = 2, 4, 5 single-GPU rates")
+    ap.add_argument("--device-point", action="store_true",
+                    help="A/B: take the LP point from a device buffer (the round-1 bracket) instead of host memory")
     ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -117,42 +179,58 @@ def main():
     from sdpcutsel_via_nn_amd import _capi, networks, synthetic
     from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector
 
-    wl = synthetic.make_workload(nb_vars=NB_VARS, k=K, count=N_PER_GPU, seed=7 + rank)
-    if rank != 0:
-        # one LP point and one objective for the whole job (rank 0's); shards differ in index sets
-        wl0 = synthetic.make_instance(NB_VARS, seed=7)
-        wl["Q_arr"], wl["vars_values"] = wl0[0], wl0[1]
-    sc = _capi.Scorer(local_rank)
-    sc.set_option(_capi.OPT_TIMING, 1)
-    if args.fuse:
-        sc.set_option(_capi.OPT_FUSE_KEYS, 1)
-    sc.set_option(_capi.OPT_KERNEL, {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[args.kernel])
-    sc.set_network(K, *networks.load_network(K))
-    sc.set_instance(NB_VARS, wl["Q_arr"])
-    sc.set_candidates(wl["set_inds"], wl["ks"], global_base=rank * N_PER_GPU)
-    d_vars = torch.from_numpy(wl["vars_values"]).to(device)
+    nb_vars, K = cfg["nb_vars"], cfg["k"]
+    n_local = cfg["per_gpu"] if cfg["per_gpu"] else cfg["total"] // world
+    kernel_opt = {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[args.kernel]
+
+    def make_scorer(k, count, seed, base):
+        """handle with the network of size k, the instance of (nb_vars, seed 7) and `count` candidates"""
+        sc = _capi.Scorer(local_rank)
+        sc.set_option(_capi.OPT_TIMING, 1)
+        if args.fuse:
+            sc.set_option(_capi.OPT_FUSE_KEYS, 1)
+        sc.set_option(_capi.OPT_KERNEL, kernel_opt)
+        sc.set_network(k, *networks.load_network(k))
+        Q_arr, vv, _ = synthetic.make_instance(nb_vars, seed=7)      # one LP point and one objective for the whole job
+        sc.set_instance(nb_vars, Q_arr)
+        sets = None
+        if args.config == "c2":
+            sets = synthetic.make_workload(nb_vars=nb_vars, k=k, count=count, seed=seed)["set_inds"]
+            sc.set_candidates(sets, np.full(count, k, dtype=np.int32), global_base=base)
+        else:
+            sc.set_candidates_philox(k, count, seed=7, first_id=base)    # index sets never exist on the host
+        return sc, Q_arr, vv, sets
+
+    sc, Q_arr, vv_host, sets_host = make_scorer(K, n_local, 7 + rank, rank * n_local)
+    d_vars = torch.from_numpy(vv_host).to(device) if args.device_point else None
     sel = None
     if world > 1 or force_sharded:
         # DeviceOps binds the library to torch's current stream: its kernels, torch's copies and the
         # hand-off to the collective are ordered without host synchronisation (a dedicated
         # non-blocking stream measured no better at N = 1 and worse with two ranks on one GPU)
-        sel = ShardedSelector(DeviceOps(sc, device), N_PER_GPU)
+        sel = ShardedSelector(DeviceOps(sc, device), n_local)
+
+    def make_step(sc, sel, kernel_ms):
+        def step():
+            if d_vars is not None:
+                sc.set_point_device(d_vars.data_ptr())
+            else:
+                sc.set_point(vv_host)          # host -> device: part of every real round (41 KB at n = 100, 4 MB at n = 1000)
+            if sel is None:
+                # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> results written
+                # by the device into the handle's pinned host block (copy=False hands out views of it)
+                res = sc.select_round(4, SEL, copy=False)
+            else:
+                # score the shard -> packed head record -> ONE all-gather (RCCL) -> replicated merge ->
+                # each rank generates the rows of its own candidates -> one D2H, one host sync
+                sc.score(_capi.EIG | _capi.NN)
+                res = sel.select_round(4, SEL)
+            kernel_ms.append(sc.last_timing()[0])
+            return res
+        return step
 
     kernel_ms = []
-
-    def step():
-        sc.set_point_device(d_vars.data_ptr())
-        if world == 1 and not force_sharded:
-            # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> one D2H
-            # (results land in the handle's pinned host block; copy=False hands out views of it)
-            res = rows = sc.select_round(4, SEL, copy=False)
-        else:
-            # score the shard -> packed head record -> ONE all-gather (RCCL) -> replicated merge ->
-            # each rank generates the rows of its own candidates -> one D2H, one host sync
-            sc.score(_capi.EIG | _capi.NN)
-            res = rows = sel.select_round(4, SEL)
-        kernel_ms.append(sc.last_timing()[0])
-        return res, rows
+    step = make_step(sc, sel, kernel_ms)
 
     # Setup, untimed: the GPU comes out of idle with low clocks and needs ~50 ms of load to reach the
     # sustained state (score kernel 0.42 -> 0.39 ms); bring it there before the W warmup steps so that
@@ -163,7 +241,8 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    for _ in range(PREWARM_STEPS):
+    prewarm = max(3, int(PREWARM_STEPS * min(1.0, 10 ** 6 / n_local)))
+    for _ in range(prewarm):
         step()
     for _ in range(args.warmup):
         step()
@@ -173,7 +252,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res, rows = step()
+        step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -184,31 +263,52 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total = N_PER_GPU * world * args.steps
+        total = n_local * world * args.steps
         k_ms = float(np.mean(kernel_ms))
-        tflops = FLOPS_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e12
-        gbs = BYTES_PER_CAND[K] * N_PER_GPU / (k_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "score_kernel_traffic.json")
-        if os.path.exists(tfile):      # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes)
+        if os.path.exists(tfile) and args.config == "c2":
+            # HBM bytes per 1e6-candidate launch of this kernel from the PMC passes kept under profiles/
+            # (separate rocprofv3 --pmc runs, gfx950 corrections); a profile figure, not measured in this run
             traffic = json.load(open(tfile)).get(args.kernel)
         out = {
             "metric": BASELINE_METRIC, "value": total / dt, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, "
-                                   "eig + neural_net_3D scoring, combined ranking sel_size=5000, cut rows",
-                       "candidates_per_gpu": N_PER_GPU, "nb_vars": NB_VARS, "k": K, "sel_size": SEL,
-                       "kernel": args.kernel, "strategy": 4},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": {"mfma": "score_mfma_kernel<3, 50, 3, %s>" % ("true" if args.fuse else "false"), "valu": "score_valu_kernel<3,50,3>", "simple": "score_simple_kernel<3>"}[args.kernel],
-                         "kernel_ms": k_ms, "flops_per_candidate": FLOPS_PER_CAND[K],
-                         "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                         "bytes_per_candidate": BYTES_PER_CAND[K]},
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["text"], "config": args.config, "candidates_per_gpu": n_local, "nb_vars": nb_vars, "k": K,
+                       "sel_size": SEL, "kernel": args.kernel, "strategy": 4,
+                       "bracket": "device point -> host results" if args.device_point else "host point -> host results"},
+            "roofline": roofline(K, n_local, k_ms, traffic),
         }
+        out["roofline"]["traffic_source"] = ("profiles/score_kernel_traffic.json (rocprofv3 --pmc passes of this kernel at "
+                                             "this size; not re-measured in this run)") if traffic else None
+        if world == 1 and args.config == "c2" and not args.no_secondary:
+            # SURVEY 8 d: "+ k = 2, 4, 5 single GPU as secondary" -- same round, same sizes, the other three networks
+            sec = {}
+            for k2 in (2, 4, 5):
+                s2, _, _, _ = make_scorer(k2, n_local, 7 + k2, 0)
+                ms2 = []
+                st2 = make_step(s2, None, ms2)
+                for _ in range(30):
+                    st2()
+                del ms2[:]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n2 = max(20, args.steps // 4)
+                for _ in range(n2):
+                    st2()
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t1
+                r2 = roofline(k2, n_local, float(np.mean(ms2)), None)
+                sec["k%d" % k2] = {"value": n_local * n2 / d2, "unit": "candidates/s", "ms_per_step": d2 / n2 * 1e3, "steps": n2,
+                                   "kernel_ms": r2["kernel_ms"], "roofline_frac": r2["frac"], "achieved_TFLOPs": r2["achieved"]}
+                s2.close()
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_sample, N_PER_GPU))
+            if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample
+                m = min(args.cpu_sample, n_local)
+                sets_host = synthetic.philox_index_sets(nb_vars, K, np.arange(m), seed=7)
+            out["cpu_baseline"] = cpu_baseline(sets_host, nb_vars, K, vv_host, Q_arr, n_local, min(args.cpu_sample, n_local))
         print(json.dumps(out), flush=True)
     sc.close()
     if use_dist:

@@ -33,7 +33,7 @@ int ensure_stage(sdpcut_ctx *h, size_t bytes)
 int ensure_pinned(sdpcut_ctx *h, size_t bytes)
 {
     if (h->pinned_bytes >= bytes) return 0;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     if (h->pinned) (void)hipHostFree(h->pinned);
     h->pinned = nullptr;
     h->pinned_dev = nullptr;
@@ -52,7 +52,7 @@ static void free_candidates(sdpcut_ctx *h);
 int alloc_candidates(sdpcut_ctx *h, int64_t N, const int64_t cnt[SDPCUT_MAX_K + 1], int64_t global_base)
 {
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     free_candidates(h);
     h->base = global_base;
     const size_t nn = (size_t)(N < 1 ? 1 : N);
@@ -134,12 +134,13 @@ int sdpcut_destroy(sdpcut_handle h)
 {
     if (!h) return SDPCUT_OK;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    sdpcut_sync(h);
     free_candidates(h);
     free_rank_ws(h);
     free_topk_ws(h);
     (void)hipFree(h->d_tri); (void)hipFree(h->d_tri_dense3);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->point_stage) (void)hipHostFree(h->point_stage);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -170,6 +171,7 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
 int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
 {
     if (!h) return SDPCUT_EINVAL;
+    if (h->point_inflight) (void)sdpcut_sync(h);     // the staging copy's transfer lives on the old stream
     h->stream = (hip_stream == SDPCUT_OWN_STREAM) ? h->own_stream : (hipStream_t)hip_stream;
     h->topk_alt_clean = false;   // its zeroing was ordered on the previous stream only
     return SDPCUT_OK;
@@ -179,7 +181,7 @@ int sdpcut_synchronize(sdpcut_handle h)
 {
     if (!h) return SDPCUT_EINVAL;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -294,7 +296,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
         }
     }
     NetHost &nh_ = h->net[k];
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     hipFree(nh_.d_blob);
     nh_.d_blob = nullptr;
     nh_.set = false;
@@ -321,7 +323,7 @@ int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr)
     if (!h) return SDPCUT_EINVAL;
     if (nb_vars < 2 || nb_vars > 40000 || !Q_arr) return sdpcut_fail(h, SDPCUT_EINVAL, "bad instance");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     const int64_t L = (int64_t)nb_vars * (nb_vars + 1) / 2;
     hipFree(h->d_Q); hipFree(h->d_vars);
     h->d_Q = nullptr; h->d_vars = nullptr; h->have_point = false; h->scored = 0;
@@ -388,9 +390,25 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
     if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "vars_values is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_vars, vars_values, (h->L + h->nb_vars) * sizeof(double), hipMemcpyHostToDevice,
-                              h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));   // caller may reuse its buffer immediately
+    // The caller's (pageable) buffer is copied into a pinned staging block and sent from there: the
+    // call returns as soon as the host copy is done -- the caller may reuse its buffer at once -- and
+    // the DMA runs behind it on the stream, in front of the score kernels (no blocking round trip
+    // per round).  The staging block is reused once the previous transfer out of it has completed.
+    const size_t bytes = (size_t)(h->L + h->nb_vars) * sizeof(double);
+    if (h->point_stage_bytes < bytes) {
+        HIP_TRY(h, sdpcut_sync(h));
+        if (h->point_stage) (void)hipHostFree(h->point_stage);
+        h->point_stage = nullptr;
+        h->point_stage_bytes = 0;
+        HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocDefault));
+        h->point_stage_bytes = bytes;
+    }
+    // (every round ends in a host wait on the stream, so this one is normally skipped; an event per
+    // transfer would put a barrier packet -- ~10 us -- in front of every score launch)
+    if (h->point_inflight) HIP_TRY(h, sdpcut_sync(h));
+    std::memcpy(h->point_stage, vars_values, bytes);
+    HIP_TRY(h, hipMemcpyAsync(h->d_vars, h->point_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    h->point_inflight = true;
     h->have_point = true;
     h->scored = 0;
     h->last_total = -1;
@@ -437,7 +455,7 @@ int sdpcut_get_scores(sdpcut_handle h, double *eigmin, double *obj_improve)
         if (!(h->scored & SDPCUT_NN)) return sdpcut_fail(h, SDPCUT_ESTATE, "optimality measure not scored");
         HIP_TRY(h, hipMemcpyAsync(obj_improve, h->d_obj, h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -487,7 +505,7 @@ int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, i
         HIP_TRY(h, hipMemcpyAsync(idx_out, d_idx, w * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(score_out, d_sc, w * 8, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -507,7 +525,7 @@ int sdpcut_rank_fetch(sdpcut_handle h, int64_t offset, int64_t count, int64_t *i
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(idx_out, d_idx, count * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(score_out, d_sc, count * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -564,7 +582,7 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
     HIP_TRY(h, hipMemcpyAsync(coef, d_coef, c * 8 * SDPCUT_ROW_LD, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(cols, d_cols, c * 8 * SDPCUT_ROW_LD, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(ks, d_ks, c * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -632,7 +650,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
         rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev);
         if (rc) return rc;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, sdpcut_sync(h));
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
     }
     if (!have) {
@@ -647,7 +665,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
             rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
             if (rc) return rc;
             HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, sdpcut_sync(h));
         }
     }
     *n_out = w;
@@ -698,7 +716,7 @@ int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho,
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(eigvals, d_w, c * D * 8, hipMemcpyDeviceToHost, h->stream));
     if (evecs) HIP_TRY(h, hipMemcpyAsync(evecs, d_v, c * D * D * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -718,7 +736,7 @@ int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs,
     rc = launch_nn_batch(h, k, count, d_in, d_out);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, d_out, c * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -728,7 +746,7 @@ int sdpcut_tri_preprocess(sdpcut_handle h, const uint8_t *adjacency, int64_t *n_
     if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!adjacency) return sdpcut_fail(h, SDPCUT_EINVAL, "adjacency is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return tri_preprocess(h, adjacency, n_triples);
 }
 
@@ -762,7 +780,7 @@ int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, do
         HIP_TRY(h, hipMemcpyAsync(entry_out, d_e, w * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(viol_out, d_v, w * 8, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     *n_written = w;
     return SDPCUT_OK;
 }
@@ -772,7 +790,7 @@ int sdpcut_last_timing(sdpcut_handle h, double *ms, int n)
     if (!h || !ms || n < 1) return SDPCUT_EINVAL;
     if (!h->timing) return sdpcut_fail(h, SDPCUT_ESTATE, "enable SDPCUT_OPT_TIMING first");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     float a = 0.f, b = 0.f;
     if (!h->timed_score || hipEventElapsedTime(&a, h->ev[0], h->ev[1]) != hipSuccess) a = -1.f;
     if (h->timing < 2 || hipEventElapsedTime(&b, h->ev[2], h->ev[3]) != hipSuccess) b = -1.f;
@@ -794,7 +812,7 @@ int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double 
     rc = launch_mfma_probe(h, dA, dB, dC);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(C, dC, 256 * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 

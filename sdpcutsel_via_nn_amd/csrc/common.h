@@ -106,7 +106,20 @@ struct sdpcut_ctx {
     void *pinned = nullptr;        // host block of sdpcut_select_round (written by the device, one sync per round)
     void *pinned_dev = nullptr;    // the same memory as the device sees it
     size_t pinned_bytes = 0;
+    // sdpcut_set_point: pinned staging copy of the caller's LP point and the event of its transfer
+    void *point_stage = nullptr;
+    size_t point_stage_bytes = 0;
+    bool point_inflight = false;   // a transfer out of point_stage may still be running
 };
+
+// every host wait on the handle's stream goes through here: it also tells sdpcut_set_point that the
+// staging copy of the previous LP point has left the host
+static inline hipError_t sdpcut_sync(sdpcut_ctx *h)
+{
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) h->point_inflight = false;
+    return e;
+}
 
 int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg);
 int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage

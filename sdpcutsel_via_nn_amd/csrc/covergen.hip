@@ -293,7 +293,7 @@ int run_cover(sdpcut_ctx *h, const std::vector<uint64_t> &adj_host, const std::v
     COVER_TRY(hipGetLastError());
     int64_t totals[5] = {0, 0, 0, 0, 0};
     COVER_TRY(hipMemcpyAsync(totals, d_off + 5 * E, 40, hipMemcpyDeviceToHost, h->stream));
-    COVER_TRY(hipStreamSynchronize(h->stream));
+    COVER_TRY(sdpcut_sync(h));
     *count_out = totals[0];
     if (totals[0] > 0x7fffffffLL) { cleanup(); return sdpcut_fail(h, SDPCUT_EINVAL, "cover has more than 2^31 - 1 candidates"); }
     if (max_subs > 0 && totals[0] >= max_subs) { cleanup(); return SDPCUT_OK; }     // count only (the reference's guard)
@@ -311,7 +311,7 @@ int run_cover(sdpcut_ctx *h, const std::vector<uint64_t> &adj_host, const std::v
         hipLaunchKernelGGL((cover_kernel<W, true>), dim3(grid), dim3(256), 0, h->stream, d_adj, d_edges, E, dim, d_per,
                            (const int64_t *)d_off, sk);
         COVER_TRY(hipGetLastError());
-        COVER_TRY(hipStreamSynchronize(h->stream));
+        COVER_TRY(sdpcut_sync(h));
     }
     cleanup();
 #undef COVER_TRY

@@ -34,7 +34,7 @@ extern "C" int sdpcut_set_candidates_philox(sdpcut_handle h, int32_t k, int64_t 
     hipLaunchKernelGGL(philox_sets_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, seed,
                        (uint64_t)first_id, N, (int)h->nb_vars, (int)k, b.d_set, b.d_orig, h->d_set_orig, h->d_k);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }
 
@@ -72,6 +72,6 @@ extern "C" int sdpcut_get_candidates(sdpcut_handle h, int64_t count, const int64
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(set_inds_out, d_out, c * 20, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(ks_out, d_k, c * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return SDPCUT_OK;
 }

@@ -249,7 +249,7 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         if (rc == 1) {
             int64_t c4[5] = {0, 0, 0, 0, 0};
             HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, sdpcut_sync(h));
             if (rank_fast_finish(h, strat, sel_size, max_out, c4, n_written, n_total, new_strat, counters_out)) return 0;
             // fewer strong candidates than sel_size: every entry is visited
             if (!c4[4] && strat == SDPCUT_STRAT_COMB) strong = c4[0];
@@ -265,7 +265,7 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         if (rc) return rc;
         int64_t c4[5] = {0, 0, 0, 0, 0};
         HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, sdpcut_sync(h));
         if (!c4[4]) {       // (void: more equal new scores at the threshold than the sort buffers hold)
             const int64_t w = n < max_out ? n : max_out;
             h->last_total = -1;
@@ -307,7 +307,7 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipMemcpyAsync(cnt, h->d_counters, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     // :654 rank_list[0:nb_violated]; class-restricted rankings list their class only
     const int64_t total = (strat == SDPCUT_STRAT_FEAS || strat == SDPCUT_PART_STRONG) ? cnt[0] : n;
     int64_t w = total < max_out ? total : max_out;

@@ -119,7 +119,7 @@ extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, in
     // stored -- with the merged ids and scores -- straight into the host block
     rc = launch_round_rows(h, sel_size, nullptr, d_mi, d_ms, coef_ld, h->pinned_dev, (int64_t)hdr_b);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     *block = h->pinned;
     return SDPCUT_OK;
 }

@@ -540,6 +540,6 @@ int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, 
     int rc = topk_select_enqueue(h, mode, k, score_add, d_idx_out, d_score_out, &d_cnt);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(cnt, d_cnt, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return 0;
 }

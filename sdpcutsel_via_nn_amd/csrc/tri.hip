@@ -99,7 +99,7 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
         HIP_TRY(h, rocprim::radix_sort_pairs_desc(h->d_tmp, tb, h->d_key_a, h->d_key_b, h->d_val_a, h->d_val_b,
                                                   (size_t)E, 0, 64, h->stream));
         HIP_TRY(h, hipMemcpyAsync(&cnt, h->d_counters, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, sdpcut_sync(h));
     }
     const int64_t w = cnt < max_out ? cnt : max_out;
     if (w > 0) {

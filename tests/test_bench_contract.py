@@ -21,7 +21,12 @@ def test_bench_names_the_baseline_metric():
     b = _baseline()
     assert bench.BASELINE_METRIC == b["metric"]
     # configs[1]: the workload the metric is quoted on
-    assert bench.N_PER_GPU == 10 ** 6 and bench.K == 3 and bench.NB_VARS == 100 and bench.SEL == 5000
+    c2 = bench.CONFIGS["c2"]
+    assert c2["per_gpu"] == 10 ** 6 and c2["k"] == 3 and c2["nb_vars"] == 100 and bench.SEL == 5000 and c2["scaling"] == "weak"
+    # configs[3]: 1e8 candidates in total over the ranks, n = 1000 (strong scaling); its 8-GPU shard
+    c4 = bench.CONFIGS["c4"]
+    assert c4["total"] == 10 ** 8 and c4["nb_vars"] == 1000 and c4["scaling"] == "strong"
+    assert bench.CONFIGS["c4-shard"]["per_gpu"] * 8 == 10 ** 8
 
 
 @pytest.mark.gpu
@@ -45,5 +50,26 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert abs(r["achieved"] - r["flops_per_candidate"] * 10 ** 6 / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-9 * r["achieved"]
     assert r["kernel_ms"] < d["ms_per_step"]
     assert r["traffic"] is None or r["traffic"] >= r["bytes_per_candidate"] * 10 ** 6
+    assert d["config"]["bracket"].startswith("host point")           # SURVEY 8 d: host to host
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "candidates/s" and c["value"] > 1e4 and c["sample"]
+    assert c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"] * 0.5
+    # SURVEY 8 d: the k = 2, 4, 5 single-GPU rates ride on the same line
+    for k in (2, 4, 5):
+        s = d["secondary"]["k%d" % k]
+        assert s["unit"] == "candidates/s" and s["value"] > 2e8 and 0.2 < s["roofline_frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_config_c4_shard():
+    """BASELINE.json configs[3] on one GPU: one of the eight shards (1.25e7 candidates of the on-device generator)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4-shard", "--steps", "3", "--warmup", "1",
+                          "--cpu-sample", "20000"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["candidates_per_gpu"] == 12_500_000 and d["config"]["nb_vars"] == 1000 and d["scaling"] == "weak"
+    assert abs(d["value"] - 12_500_000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["value"] > 5e8
+    assert d["roofline"]["candidates_per_launch"] == 12_500_000 and 0.2 < d["roofline"]["frac"] < 1.0
+    assert d["cpu_baseline"]["value"] > 1e4

