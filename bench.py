@@ -134,7 +134,12 @@ def main():
     ap.add_argument("--device-point", action="store_true",
                     help="A/B: take the LP point from a device buffer (the round-1 bracket) instead of host memory")
     ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
+    ap.add_argument("--no-auto-regime", action="store_true",
+                    help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
+    ap.add_argument("--k", type=int, choices=[2, 3, 4, 5], default=None, help="candidate size (default: the config's, 3)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="attach the HIP event pair to the score dispatch of every n-th step of the timed region")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -179,16 +184,17 @@ def main():
     from sdpcutsel_via_nn_amd import _capi, networks, synthetic
     from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector
 
-    nb_vars, K = cfg["nb_vars"], cfg["k"]
+    nb_vars, K = cfg["nb_vars"], args.k or cfg["k"]
     n_local = cfg["per_gpu"] if cfg["per_gpu"] else cfg["total"] // world
     kernel_opt = {"mfma": _capi.KERNEL_MFMA, "simple": _capi.KERNEL_SIMPLE, "valu": _capi.KERNEL_VALU}[args.kernel]
 
     def make_scorer(k, count, seed, base):
         """handle with the network of size k, the instance of (nb_vars, seed 7) and `count` candidates"""
         sc = _capi.Scorer(local_rank)
-        sc.set_option(_capi.OPT_TIMING, 1)
         if args.fuse:
             sc.set_option(_capi.OPT_FUSE_KEYS, 1)
+        if args.no_auto_regime:
+            sc.set_option(_capi.OPT_AUTO_REGIME, 0)
         sc.set_option(_capi.OPT_KERNEL, kernel_opt)
         sc.set_network(k, *networks.load_network(k))
         Q_arr, vv, _ = synthetic.make_instance(nb_vars, seed=7)      # one LP point and one objective for the whole job
@@ -211,7 +217,16 @@ def main():
         sel = ShardedSelector(DeviceOps(sc, device), n_local)
 
     def make_step(sc, sel, kernel_ms):
+        """One round.  The score kernel's duration is measured live with a HIP event pair attached to its
+        dispatch (hipExtLaunchKernelGGL) on every `--time-every`-th step: the pair and its read-back cost the
+        host ~10 us, which a production round does not pay, so it rides on a sample of the timed steps."""
+        counter = [0]
+
         def step():
+            timed = counter[0] % args.time_every == 0
+            counter[0] += 1
+            if timed:
+                sc.set_option(_capi.OPT_TIMING, 1)
             if d_vars is not None:
                 sc.set_point_device(d_vars.data_ptr())
             else:
@@ -225,8 +240,11 @@ def main():
                 # each rank generates the rows of its own candidates -> one D2H, one host sync
                 sc.score(_capi.EIG | _capi.NN)
                 res = sel.select_round(4, SEL)
-            kernel_ms.append(sc.last_timing()[0])
+            if timed:
+                kernel_ms.append(sc.last_timing()[0])
+                sc.set_option(_capi.OPT_TIMING, 0)
             return res
+        step.counter = counter
         return step
 
     kernel_ms = []
@@ -247,6 +265,7 @@ def main():
     for _ in range(args.warmup):
         step()
     del kernel_ms[:]
+    step.counter[0] = 0          # the first step of the timed region carries an event pair
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -267,7 +286,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "score_kernel_traffic.json")
-        if os.path.exists(tfile) and args.config == "c2":
+        if os.path.exists(tfile) and args.config == "c2" and K == 3:
             # HBM bytes per 1e6-candidate launch of this kernel from the PMC passes kept under profiles/
             # (separate rocprofv3 --pmc runs, gfx950 corrections); a profile figure, not measured in this run
             traffic = json.load(open(tfile)).get(args.kernel)
@@ -280,6 +299,7 @@ def main():
                        "bracket": "device point -> host results" if args.device_point else "host point -> host results"},
             "roofline": roofline(K, n_local, k_ms, traffic),
         }
+        out["roofline"]["kernel_ms_samples"] = len(kernel_ms)
         out["roofline"]["traffic_source"] = ("profiles/score_kernel_traffic.json (rocprofv3 --pmc passes of this kernel at "
                                              "this size; not re-measured in this run)") if traffic else None
         if world == 1 and args.config == "c2" and not args.no_secondary:
@@ -292,6 +312,7 @@ def main():
                 for _ in range(30):
                     st2()
                 del ms2[:]
+                st2.counter[0] = 0
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 n2 = max(20, args.steps // 4)

@@ -59,7 +59,11 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * over the scores.  Default 0: on MI355X the two variants take the same time per round (the
  * separate pass costs 16 us, the fused epilogue 15 us), and the unfused score kernel is the
  * cleaner unit to measure. */
-enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3 };
+/* SDPCUT_OPT_AUTO_REGIME (default 1): sdpcut_select_round with the combined strategy lets the score
+ * kernels count the strong candidates and the selection pick its regime on the device (one selection,
+ * no host round trip whether or not sel_size strong candidates exist).  0: the selection assumes the
+ * common regime and the host repeats it when the count says otherwise (the round-1 behaviour). */
+enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4 };
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
 #define SDPCUT_MAX_K 5

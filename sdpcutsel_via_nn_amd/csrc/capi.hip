@@ -18,6 +18,26 @@ int sdpcut_fail(sdpcut_ctx *h, int code, const std::string &msg)
     return code;
 }
 
+// Host wait for the serial number the last workgroup of a round's epilogue stores (system scope, after
+// its results) into pinned memory.  Bounded: after ~2 s without the word the stream is synchronised
+// the ordinary way, which also surfaces a faulted kernel as an error.
+int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial)
+{
+    const volatile int64_t *w = (const volatile int64_t *)word;
+    for (long spin = 0; spin < 400000000L; ++spin) {
+        if (*w == serial) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            h->point_inflight = false;      // the round ran behind the point's transfer
+            return 0;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(h->stream) != hipErrorNotReady) break;
+    }
+    HIP_TRY(h, sdpcut_sync(h));
+    if (*w != serial) return sdpcut_fail(h, SDPCUT_EHIP, "round epilogue did not report completion");
+    return 0;
+}
+
 int ensure_stage(sdpcut_ctx *h, size_t bytes)
 {
     if (bytes <= h->stage_bytes) return 0;
@@ -40,6 +60,7 @@ int ensure_pinned(sdpcut_ctx *h, size_t bytes)
     h->pinned_bytes = 0;
     HIP_TRY(h, hipHostMalloc(&h->pinned, bytes, hipHostMallocMapped));
     HIP_TRY(h, hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0));
+    std::memset(h->pinned, 0, bytes < 64 ? bytes : 64);     // header incl. the completion word of wait_round_done
     h->pinned_bytes = bytes;
     return 0;
 }
@@ -141,6 +162,7 @@ int sdpcut_destroy(sdpcut_handle h)
     (void)hipFree(h->d_tri); (void)hipFree(h->d_tri_dense3);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->point_stage) (void)hipHostFree(h->point_stage);
+    (void)hipFree(h->d_done_ticket);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -160,6 +182,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         return SDPCUT_OK;
     case SDPCUT_OPT_FUSE_KEYS:
         h->fuse_keys = value != 0;
+        return SDPCUT_OK;
+    case SDPCUT_OPT_AUTO_REGIME:
+        h->auto_regime = value != 0;
         return SDPCUT_OK;
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
@@ -398,16 +423,22 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
     if (h->point_stage_bytes < bytes) {
         HIP_TRY(h, sdpcut_sync(h));
         if (h->point_stage) (void)hipHostFree(h->point_stage);
+    (void)hipFree(h->d_done_ticket);
         h->point_stage = nullptr;
         h->point_stage_bytes = 0;
-        HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocMapped));
+        HIP_TRY(h, hipHostGetDevicePointer(&h->point_stage_dev, h->point_stage, 0));
         h->point_stage_bytes = bytes;
     }
-    // (every round ends in a host wait on the stream, so this one is normally skipped; an event per
+    // (every round ends in a host wait on the device, so this one is normally skipped; an event per
     // transfer would put a barrier packet -- ~10 us -- in front of every score launch)
     if (h->point_inflight) HIP_TRY(h, sdpcut_sync(h));
     std::memcpy(h->point_stage, vars_values, bytes);
-    HIP_TRY(h, hipMemcpyAsync(h->d_vars, h->point_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    // a kernel of the compute queue pulls the block over PCIe (mapped host memory): the score launch
+    // follows it in queue order, whereas a copy-engine transfer costs a cross-queue hand-off (~10 us)
+    // in front of every round
+    int rc = launch_point_copy(h, (const double *)h->point_stage_dev, h->L + h->nb_vars);
+    if (rc) return rc;
     h->point_inflight = true;
     h->have_point = true;
     h->scored = 0;
@@ -601,7 +632,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
                           : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
     int rc;
     int64_t cap = sel_size < h->N ? sel_size : h->N;
-    bool keys_done = false;
+    int stage = 0;               // how far the selection's first pass has got (topk_select_enqueue)
+    bool auto_regime = false;
     if (h->fuse_keys && (h->scored & need) == 0 && rank_fast_mode(h, strat, sel_size, cap, nullptr)) {
         // nothing scored at this point yet and the head comes from the radix select: let the score
         // kernels run the selection's first pass (keys, leading digit, class counters) as well
@@ -610,9 +642,25 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         fuse.k = cap;
         rc = topk_begin(h, &fuse.ws, &fuse.keys);
         if (rc) return rc;
+        bool keys_done = false;
         rc = launch_score(h, need, &fuse, &keys_done);
         if (rc) return rc;
         h->scored |= need;
+        stage = keys_done ? 2 : 1;
+    } else if (h->auto_regime && strat == SDPCUT_STRAT_COMB && (h->scored & need) == 0 &&
+               rank_fast_mode(h, strat, sel_size, cap, nullptr)) {
+        // combined strategy, both measures scored in this call: the score kernels count the strong
+        // candidates into the selection's workspace, and the selection resolves its regime on the
+        // device (at least sel_size strong ones: those, + BIG_M; fewer: every entry visited) -- one
+        // selection and no host round trip in either regime
+        void *ws = nullptr;
+        rc = topk_begin(h, &ws, nullptr);
+        if (rc) return rc;
+        rc = launch_score(h, need, nullptr, nullptr, topk_strong_counter(ws));
+        if (rc) return rc;
+        h->scored |= need;
+        stage = 1;
+        auto_regime = true;
     } else if ((h->scored & need) != need) {
         rc = sdpcut_score(h, need & ~h->scored);
         if (rc) return rc;
@@ -643,14 +691,19 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
     // results directly into the pinned host block (no copy engine); one synchronisation
     const int64_t *d_cnt = nullptr;
-    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, keys_done);
+    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, stage, auto_regime);
     if (rc < 0) return rc;
     const bool fast_tried = rc == 1;
     if (fast_tried) {
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
-        rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev);
+        // the epilogue's last workgroup publishes this round's serial number in the block's header: the
+        // host polls that word instead of waiting for the runtime's completion signal (~5 us earlier)
+        int64_t *hdr = (int64_t *)h->pinned;
+        const int64_t serial = ++h->round_serial;
+        rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
         if (rc) return rc;
-        HIP_TRY(h, sdpcut_sync(h));
+        rc = wait_round_done(h, hdr + 7, serial);
+        if (rc) return rc;
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
     }
     if (!have) {

@@ -53,6 +53,7 @@ struct sdpcut_ctx {
     std::string err;
     int kernel_variant = SDPCUT_KERNEL_MFMA;
     bool fuse_keys = false;        // SDPCUT_OPT_FUSE_KEYS (measured: no gain, see include/sdpcut.h)
+    bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch
@@ -107,9 +108,11 @@ struct sdpcut_ctx {
     void *pinned_dev = nullptr;    // the same memory as the device sees it
     size_t pinned_bytes = 0;
     // sdpcut_set_point: pinned staging copy of the caller's LP point and the event of its transfer
-    void *point_stage = nullptr;
+    void *point_stage = nullptr, *point_stage_dev = nullptr;
     size_t point_stage_bytes = 0;
     bool point_inflight = false;   // a transfer out of point_stage may still be running
+    int64_t round_serial = 0;      // completion word of the fused round (round_rows_kernel -> pinned header)
+    uint32_t *d_done_ticket = nullptr;
 };
 
 // every host wait on the handle's stream goes through here: it also tells sdpcut_set_point that the
@@ -144,13 +147,18 @@ struct ScoreFuse {
     int mode;      // TK_MODE_* of topk_dev.h
     int64_t k;     // head length asked from the selection
 };
-int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse = nullptr, bool *fused = nullptr);
+// strong_out (optional, device, 8 int64 replicas): the launches add the number of candidates with
+// obj_improve > 0 and lambda_min < -1e-15 to strong_out[workgroup % 8] (needs both flags; used by the device-resolved combined selection)
+int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse = nullptr, bool *fused = nullptr,
+                 int64_t *strong_out = nullptr);
 int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
                     double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks);
 // Epilogue of a fused round: rows of the ranking head + its ids, scores and the four counters,
 // written to `block` (device view of the pinned host block; layout of sdpcut_select_round_view).
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
-                      int coef_ld, void *block, int64_t hdr_bytes = 64);
+                      int coef_ld, void *block, int64_t hdr_bytes = 64, int64_t done_serial = 0);
+int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n);
+int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial);   // capi.hip
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
                      double *d_vals, double *d_vecs);
 int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);
@@ -167,11 +175,13 @@ int gather_scores_on_device(sdpcut_ctx *h, int64_t count, const int64_t *d_ids, 
 int rank_fetch_on_device(sdpcut_ctx *h, int64_t offset, int64_t count, int64_t *d_idx_out, double *d_score_out);
 void free_rank_ws(sdpcut_ctx *h);
 
+// stage: see topk_select_enqueue; auto_regime: the combined strategy's regime is resolved on the device
+// from the strong count the score kernels of this round left in the selection workspace
 int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
-                      double *d_score_out, const int64_t **d_c4, bool keys_done = false);
+                      double *d_score_out, const int64_t **d_c4, int stage = 0, bool auto_regime = false);
 // TK_MODE_* the fast path would use for this request, 0 if it is not eligible
 int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, double *score_add);
-int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[5],
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[7],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out);
 
 // tri.hip
@@ -181,11 +191,12 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
 
 // topk.hip
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                        double *d_score_out, const int64_t **d_counters_out, bool keys_done = false);
+                        double *d_score_out, const int64_t **d_counters_out, int stage = 0, int64_t sel = 0);
 // allocate / zero (or swap in the pre-zeroed) workspace of the next selection and return it together
 // with the key array: what a score launch needs to run the selection's first pass itself
 // (ScoreFuse); follow with topk_select_enqueue(..., keys_done = true)
 int topk_begin(sdpcut_ctx *h, void **ws, uint64_t **keys);
+int64_t *topk_strong_counter(void *ws);      // TopkWs::strong_rep (TK_SREP = 8 replicas) of a workspace handed out by topk_begin
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[5]);
 void free_topk_ws(sdpcut_ctx *h);

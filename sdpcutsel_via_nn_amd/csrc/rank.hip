@@ -192,26 +192,30 @@ int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
 }
 
 int rank_fast_enqueue(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
-                      double *d_score_out, const int64_t **d_c4, bool keys_done)
+                      double *d_score_out, const int64_t **d_c4, int stage, bool auto_regime)
 {
     double add = 0.0;
-    const int mode = rank_fast_mode(h, strat, sel_size, max_out, &add);
+    int mode = rank_fast_mode(h, strat, sel_size, max_out, &add);
     if (!mode) return 0;
-    int rc = topk_select_enqueue(h, mode, max_out, add, d_idx_out, d_score_out, d_c4, keys_done);
+    int64_t sel = sel_size < h->N ? sel_size : h->N;
+    if (auto_regime && strat == SDPCUT_STRAT_COMB) mode = 5 /* TK_MODE_COMBAUTO */;
+    int rc = topk_select_enqueue(h, mode, max_out, add, d_idx_out, d_score_out, d_c4, stage, sel);
     return rc ? rc : 1;
 }
 
 // Host side of the fast path once the counters are on the host ({class size, nb_violated,
-// nb_positive, k_eff, void flag}).  Returns 1 if the enqueued selection is the answer, 0 if the
-// general path has to run (combined scan visiting everything, or a selection that gave up).
-int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[5],
+// nb_positive, k_eff, void flag, strong count, mode}).  Returns 1 if the enqueued selection is the
+// answer, 0 if the general path has to run (a selection that gave up; the combined scan visiting
+// everything when the regime was not resolved on the device).
+int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, const int64_t c4[7],
                      int64_t *n_written, int64_t *n_total, int32_t *new_strat, int64_t *counters_out)
 {
     const int64_t n = h->N;
     if (sel_size > n) sel_size = n;
     const bool comb = strat == SDPCUT_STRAT_COMB;
     if (c4[4]) return 0;
-    if (comb && c4[0] < sel_size) return 0;
+    const bool all_visited = comb && c4[6] == 4 /* TK_MODE_COMBALL: resolved on the device, strong < sel_size */;
+    if (comb && !all_visited && c4[0] < sel_size) return 0;
     const int64_t total = (strat == SDPCUT_STRAT_OPT || comb) ? n : c4[0];
     const int64_t w = total < max_out ? total : max_out;
     h->last_total = -1;                     // only the head exists: nothing to fetch later
@@ -220,6 +224,7 @@ int rank_fast_finish(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out
     int64_t cnt[4] = {c4[1], 0, 0, c4[2]};
     if (strat == SDPCUT_STRAT_FEAS || strat == SDPCUT_PART_STRONG) cnt[0] = c4[0];
     if (comb) { cnt[1] = sel_size; cnt[2] = sel_size; }
+    if (all_visited) { cnt[1] = c4[5]; cnt[2] = c4[1]; }     // every violated entry is seen by the scan
     if (new_strat) {
         *new_strat = strat;
         if (comb && (double)cnt[1] / (double)sel_size < (double)cnt[2] / (double)n) *new_strat = SDPCUT_STRAT_FEAS;
@@ -247,7 +252,7 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         rc = rank_fast_enqueue(h, strat, sel_size, max_out, d_idx_out, d_score_out, &d_c4);
         if (rc < 0) return rc;
         if (rc == 1) {
-            int64_t c4[5] = {0, 0, 0, 0, 0};
+            int64_t c4[7] = {0, 0, 0, 0, 0, 0, 0};
             HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, sdpcut_sync(h));
             if (rank_fast_finish(h, strat, sel_size, max_out, c4, n_written, n_total, new_strat, counters_out)) return 0;

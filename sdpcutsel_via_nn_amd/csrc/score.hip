@@ -44,6 +44,10 @@ struct ScoreArgs {
     int tk_mode;
     int64_t tk_k;
     uint32_t tk_blocks;    // blocks of ALL score launches of this call (ticket target of the pass)
+    // optional: += number of candidates with obj_improve > 0 and lambda_min < -1e-15 (the "strong" class
+    // of the combined strategy, cut_select_qp.py:607-613); lets the selection that follows pick its
+    // regime on the device.  Needs both flags.
+    int64_t *strong_out;
     NetDev net;
 };
 
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     __shared__ uint32_t tk_hist[256];
     __shared__ uint32_t tk_cnt[3];
     uint32_t c_class = 0, c_viol = 0, c_pos = 0;
+    uint32_t c_strong = 0;        // per wave (lane 0 keeps it)
     if constexpr (FUSE) {
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 3) tk_cnt[threadIdx.x] = 0;
@@ -611,6 +616,8 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             double obj = cd.negSM;
             obj = obj + y * cd.max_elem;
             if (valid) A.obj_out[out_idx] = obj;
+            if (A.strong_out)       // uniform
+                c_strong += (uint32_t)__popcll(__ballot(valid && obj > 0.0 && lam < SDPCUT_NEG_EIGVAL));
             if constexpr (FUSE) {
                 const bool have_eig = (A.flags & SDPCUT_EIG) != 0;
                 uint64_t key = 0;
@@ -628,6 +635,16 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         PHASE_MARK(4);
     }
     PHASE_REPORT;
+    if (A.strong_out) {      // uniform: one no-return atomic per workgroup, into one of eight replicas
+        __shared__ uint32_t s_strong;
+        if (threadIdx.x == 0) s_strong = 0;
+        __syncthreads();
+        if (lane == 0 && c_strong) atomicAdd(&s_strong, c_strong);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_strong)
+            __hip_atomic_fetch_add((unsigned long long *)&A.strong_out[blockIdx.x & 7], (unsigned long long)s_strong,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (FUSE) {   // same tail as tk_keys_kernel: class counters, then the pass hand-off
         if (c_class) atomicAdd(&tk_cnt[0], c_class);
         if (c_viol) atomicAdd(&tk_cnt[1], c_viol);
@@ -765,6 +782,12 @@ __global__ __launch_bounds__(256, (H > 56 ? 1 : 2)) void score_valu_kernel(Score
             if (A.flags & SDPCUT_EIG) A.eig_out[out_idx] = lam;
             if (A.flags & SDPCUT_NN) A.obj_out[out_idx] = obj;
         }
+        if (A.strong_out) {
+            const unsigned long long m = __ballot(valid && obj > 0.0 && lam < SDPCUT_NEG_EIGVAL);
+            if ((threadIdx.x & 63) == 0 && m)
+                __hip_atomic_fetch_add((unsigned long long *)&A.strong_out[blockIdx.x & 7], (unsigned long long)__popcll(m),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -786,8 +809,10 @@ __global__ __launch_bounds__(64) void score_simple_kernel(ScoreArgs A)
         Cand<K> cd;
         gather_candidate<K>(cd, A.set, A.n, cc, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
         const int32_t out_idx = A.orig[cc];
+        double lam_c = 0.0;
         if (A.flags & SDPCUT_EIG) {
             const double lam = candidate_eigmin<K>(cd);
+            lam_c = lam;
             if (valid) A.eig_out[out_idx] = lam;
         }
         if (!(A.flags & SDPCUT_NN)) continue;
@@ -818,6 +843,12 @@ __global__ __launch_bounds__(64) void score_simple_kernel(ScoreArgs A)
             double obj = cd.negSM;
             obj = obj + y * cd.max_elem;
             if (valid) A.obj_out[out_idx] = obj;
+            if (A.strong_out) {
+                const unsigned long long m = __ballot(valid && obj > 0.0 && lam_c < SDPCUT_NEG_EIGVAL);
+                if (lane == 0 && m)
+                    __hip_atomic_fetch_add((unsigned long long *)&A.strong_out[blockIdx.x & 7], (unsigned long long)__popcll(m),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -968,7 +999,8 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
                                                         const double *score, int64_t idx_base, int64_t n_local,
                                                         const int32_t *set5, const int32_t *ks, const double *vars,
                                                         int32_t nv, int64_t L, int coef_ld, char *block,
-                                                        int64_t hdr_bytes, uint64_t *zero_ptr, int zero_words)
+                                                        int64_t hdr_bytes, uint64_t *zero_ptr, int zero_words,
+                                                        int64_t done_serial, uint32_t *done_ticket)
 {
     __shared__ double tile[64 * SDPCUT_ROW_LD];
     const int lane = threadIdx.x;
@@ -982,7 +1014,7 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
     int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
     int64_t limit = cap;
     if (d_c4) {
-        if (blockIdx.x == 0 && lane < 5) o_c4[lane] = d_c4[lane];
+        if (blockIdx.x == 0 && lane < 7) o_c4[lane] = d_c4[lane];     // counters, strong count, mode (TopkWs::counters)
         limit = d_c4[3];
         if (limit > cap) limit = cap;
     }
@@ -1020,6 +1052,25 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
     const int64_t nlive = (limit - first < 64) ? limit - first : 64;
     const int total = nlive > 0 ? (int)nlive * coef_ld : 0;
     for (int w = lane; w < total; w += 64) o_coef[first * coef_ld + w] = tile[w];
+    if (done_serial) {
+        // completion word for the polling host: every workgroup makes its stores to the host block
+        // visible system-wide, then takes a ticket; the last one publishes the round's serial number
+        __threadfence_system();
+        if (lane == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next round
+                __threadfence_system();
+                __hip_atomic_store(o_c4 + 7, done_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// LP point: mapped host memory -> device table (sdpcut_set_point)
+__global__ __launch_bounds__(256) void point_copy_kernel(const double *src, double *dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1087,6 +1138,9 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double *Am, const 
 #ifndef SDPCUT_MFMA_BLOCKS_PER_CU
 #define SDPCUT_MFMA_BLOCKS_PER_CU 8
 #endif
+#ifndef SDPCUT_FUSE_BLOCKS_PER_CU
+#define SDPCUT_FUSE_BLOCKS_PER_CU 2
+#endif
 
 static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
 {
@@ -1118,7 +1172,7 @@ static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
 
 template <int K>
 static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
-                          const ScoreFuse *fuse, uint32_t fuse_blocks)
+                          const ScoreFuse *fuse, uint32_t fuse_blocks, int64_t *strong_out)
 {
     const Bucket &b = h->bucket[K];
     if (b.n == 0) return 0;
@@ -1131,6 +1185,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.tk_mode = fuse ? fuse->mode : 0;
     A.tk_k = fuse ? fuse->k : 0;
     A.tk_blocks = fuse_blocks;
+    A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
     A.net = h->net[K].dev;
     if ((flags & SDPCUT_NN) && !h->net[K].set)
         return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
@@ -1144,7 +1199,10 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         if (K == 5) SCORE_LAUNCH((score_valu_kernel<5, 64, 4>), grid, 256);
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
-        const int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
+        // With the fused key pass every workgroup ends with a histogram flush and a ticket: launch only
+        // the workgroups that are resident together (2 per CU), each looping over its tiles, so that the
+        // flush is paid once per resident workgroup, in the kernel's ragged tail.
+        const int grid = grid_for(h, ntiles, A.tk ? SDPCUT_FUSE_BLOCKS_PER_CU : SDPCUT_MFMA_BLOCKS_PER_CU);
         if (A.tk) {
             if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true>), grid, 256);
             if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
@@ -1165,7 +1223,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     return 0;
 }
 
-int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused)
+int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused, int64_t *strong_out)
 {
     // the fused key pass lives in the MFMA kernel only: every non-empty size class must run on it;
     // the last block over ALL launches resolves the digit, so it needs the total block count
@@ -1176,7 +1234,7 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
         for (int k = 2; k <= SDPCUT_MAX_K && ok; ++k) {
             if (h->bucket[k].n == 0) continue;
             ok = net_shape_ok(h, k, flags);
-            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
+            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, SDPCUT_FUSE_BLOCKS_PER_CU);
         }
         if (!ok || fuse_blocks == 0) fuse = nullptr;
         else if (fused) *fused = true;
@@ -1189,10 +1247,10 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
     hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
     if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
     int rc;
-    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, fuse_blocks))) return rc;
-    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, fuse_blocks))) return rc;
-    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, fuse_blocks))) return rc;
-    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, fuse_blocks))) return rc;
+    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, fuse_blocks, strong_out))) return rc;
+    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, fuse_blocks, strong_out))) return rc;
+    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, fuse_blocks, strong_out))) return rc;
+    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, fuse_blocks, strong_out))) return rc;
     return 0;
 }
 
@@ -1208,17 +1266,31 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
     return 0;
 }
 
+int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n)
+{
+    int64_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(point_copy_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, h->stream, src_mapped, h->d_vars, n);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
-                      int coef_ld, void *block, int64_t hdr_bytes)
+                      int coef_ld, void *block, int64_t hdr_bytes, int64_t done_serial)
 {
     if (cap <= 0) return 0;
+    if (done_serial && !h->d_done_ticket) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_done_ticket, 64));
+        HIP_TRY(h, hipMemsetAsync(h->d_done_ticket, 0, 64, h->stream));
+    }
     uint64_t *zp = nullptr;
     int zw = 0;
     int rc = topk_alt_ws(h, &zp, &zw);
     if (rc) return rc;
     const int grid = (int)((cap + 63) / 64);
     hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
-                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw);
+                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw, done_serial,
+                       h->d_done_ticket);
     HIP_TRY(h, hipGetLastError());
     h->topk_alt_clean = true;
     return 0;

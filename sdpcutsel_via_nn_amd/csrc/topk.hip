@@ -22,11 +22,12 @@
 #include "topk_dev.h"
 
 // pass 0: build the keys, histogram of digit 7, class / violated / positive counts
-__global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n, int64_t k, const double *eig,
+__global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t sel, int64_t n, int64_t k, const double *eig,
                                                              const double *obj, uint64_t *keys, TopkWs *ws)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cnt[3];
+    mode = resolve_mode(mode, ws, sel);      // uniform over the grid: counters[5] is final before this launch
     hist[threadIdx.x] = 0;
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -65,7 +66,11 @@ __global__ __launch_bounds__(TK_THREADS) void tk_keys_kernel(int mode, int64_t n
     __syncthreads();
     if (threadIdx.x < 3 && cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&ws->counters[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) st_i64(&ws->mode, mode);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st_i64(&ws->mode, mode);
+        st_i64(&ws->counters[6], mode);
+        st_i64(&ws->counters[5], strong_total(ws));      // for the host (round header)
+    }
     finish_pass(ws, 0, k, hist, gridDim.x);
 }
 
@@ -285,12 +290,10 @@ __device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb,
 }
 
 template <bool TIE>
-__global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *ws, const uint64_t *sel_key,
-                                                                 const uint32_t *sel_idx, uint64_t *tile_key,
-                                                                 uint32_t *tile_idx, const double *obj)
+__device__ __forceinline__ void tilesort_body(const TopkWs *ws, const uint64_t *sel_key, const uint32_t *sel_idx,
+                                              uint64_t *tile_key, uint32_t *tile_idx, const double *obj, uint64_t *sk,
+                                              uint32_t *si)
 {
-    __shared__ uint64_t sk[TK_TILE];
-    __shared__ uint32_t si[TK_TILE];
     const int k_eff = (int)ws->n_sel;              // compacted entries (a superset of the head after an early stop)
     const int lo = blockIdx.x * TK_TILE;
     if (lo >= k_eff) return;                       // uniform
@@ -321,28 +324,28 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
     }
 }
 
-template <bool TIE>
-__global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
-                                                                  const uint64_t *tile_key, const uint32_t *tile_idx,
-                                                                  int64_t *idx_out, double *score_out, const double *obj,
-                                                                  int64_t *rec_hdr, int64_t rec_count, int64_t rec_len)
+// TIE: 0 plain composite compare, 1 obj_improve as tie key (mode COMBALL), 2 decided by the mode the
+// selection resolved on the device (TK_MODE_COMBAUTO): one uniform branch at entry picks the
+// specialised body, the comparators stay branch-free
+template <int TIE>
+__global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *ws, const uint64_t *sel_key,
+                                                                 const uint32_t *sel_idx, uint64_t *tile_key,
+                                                                 uint32_t *tile_idx, const double *obj)
 {
-    __shared__ uint64_t sk[TK_MAXK];
-    __shared__ uint32_t si[TK_MAXK];
+    __shared__ uint64_t sk[TK_TILE];
+    __shared__ uint32_t si[TK_TILE];
+    if (TIE == 1 || (TIE == 2 && ws->mode == TK_MODE_COMBALL))
+        tilesort_body<true>(ws, sel_key, sel_idx, tile_key, tile_idx, obj, sk, si);
+    else
+        tilesort_body<false>(ws, sel_key, sel_idx, tile_key, tile_idx, obj, sk, si);
+}
+
+template <bool TIE>
+__device__ __forceinline__ void mergerank_body(int64_t base, double score_add, const TopkWs *ws, const uint64_t *tile_key,
+                                               const uint32_t *tile_idx, int64_t *idx_out, double *score_out,
+                                               const double *obj, uint64_t *sk, uint32_t *si)
+{
     const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
-    if (rec_hdr) {
-        // shard record (shard.hip): this launch also writes the 8-word header in front of the head
-        // and pads the slots behind the entries it emits with (-inf, INT64_MAX); rec_len >= 0 is the
-        // length of the shard's list when that is not the class size (optimality ranking)
-        const int64_t g = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-        const int64_t written = ws->counters[4] ? 0 : ws->counters[3];
-        if (g < rec_count && g >= written) {
-            score_out[g] = -__builtin_huge_val();
-            idx_out[g] = 0x7fffffffffffffffLL;
-        }
-        if (g < 8)
-            rec_hdr[g] = g == 0 ? (rec_len >= 0 ? rec_len : ws->counters[0]) : g <= 4 ? ws->counters[g] : 0;
-    }
     if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
     const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
     for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 8 * TK_THREADS) {      // 8 loads in flight per thread
@@ -384,6 +387,35 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
     if (rank >= k_eff) return;                                // superset entries beyond the head
     idx_out[rank] = base + (int64_t)ie;
     score_out[rank] = score_of(~ke) + score_add;
+}
+
+template <int TIE>
+__global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, double score_add, const TopkWs *ws,
+                                                                  const uint64_t *tile_key, const uint32_t *tile_idx,
+                                                                  int64_t *idx_out, double *score_out, const double *obj,
+                                                                  int64_t *rec_hdr, int64_t rec_count, int64_t rec_len)
+{
+    __shared__ uint64_t sk[TK_MAXK];
+    __shared__ uint32_t si[TK_MAXK];
+    if (rec_hdr) {
+        // shard record (shard.hip): this launch also writes the 8-word header in front of the head
+        // and pads the slots behind the entries it emits with (-inf, INT64_MAX); rec_len >= 0 is the
+        // length of the shard's list when that is not the class size (optimality ranking)
+        const int64_t g = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+        const int64_t written = ws->counters[4] ? 0 : ws->counters[3];
+        if (g < rec_count && g >= written) {
+            score_out[g] = -__builtin_huge_val();
+            idx_out[g] = 0x7fffffffffffffffLL;
+        }
+        if (g < 8)
+            rec_hdr[g] = g == 0 ? (rec_len >= 0 ? rec_len : ws->counters[0]) : g <= 4 ? ws->counters[g] : 0;
+    }
+    if (TIE == 1 || (TIE == 2 && ws->mode == TK_MODE_COMBALL)) {
+        // (device-resolved regime: BIG_M belongs to the strong class only, not to COMBALL's own scores)
+        mergerank_body<true>(base, TIE == 2 ? 0.0 : score_add, ws, tile_key, tile_idx, idx_out, score_out, obj, sk, si);
+    } else {
+        mergerank_body<false>(base, score_add, ws, tile_key, tile_idx, idx_out, score_out, obj, sk, si);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -434,15 +466,18 @@ int topk_begin(sdpcut_ctx *h, void **ws_out, uint64_t **keys_out)
     return 0;
 }
 
+int64_t *topk_strong_counter(void *ws) { return ((TopkWs *)ws)->strong_rep; }
+
 // Lists that fit the sort buffers whole (n <= 8192 -- most of the reference's BoxQP / QCQP instances)
 // need no radix passes: ONE workgroup builds the keys, counts the class and compacts its members;
 // the sort that follows orders all of them and emits the first k_eff.  Three launches instead of
 // seven on the latency-bound end of the problem sizes.
-__global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t n, int64_t k, const double *eig,
+__global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t sel, int64_t n, int64_t k, const double *eig,
                                                               const double *obj, TopkWs *ws, uint64_t *sel_key,
                                                               uint32_t *sel_idx)
 {
     __shared__ uint32_t cnt[4];      // class members, violated, positive, next slot
+    mode = resolve_mode(mode, ws, sel);
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -477,32 +512,37 @@ __global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t 
         ws->counters[3] = k < cls ? k : cls;
         ws->n_sel = cls;
         ws->mode = mode;
+        ws->counters[6] = mode;
+        ws->counters[5] = strong_total(ws);
     }
 }
 
-// keys_done: the score kernels already ran pass 0 (keys, leading digit, class counters) on the
-// workspace handed out by topk_begin.
+// stage 0: fresh selection; 1: the workspace has been handed out by topk_begin already (the score
+// kernels left their strong count in it); 2: the score kernels also ran pass 0 (keys, leading digit,
+// class counters).  mode TK_MODE_COMBAUTO: resolved by the first pass against `sel` (stage 1 only).
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
-                        double *d_score_out, const int64_t **d_counters_out, bool keys_done)
+                        double *d_score_out, const int64_t **d_counters_out, int stage, int64_t sel)
 {
     const int64_t n = h->N;
     if (k < 1 || k > TK_MAXK || n < 1) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k out of range");
+    if (mode == TK_MODE_COMBAUTO && stage != 1) return sdpcut_fail(h, SDPCUT_ESTATE, "top-k select: no strong count");
     int rc = 0;
-    if (!keys_done) {
+    if (stage == 0) {
         rc = topk_begin(h, nullptr, nullptr);
         if (rc) return rc;
     }
+    const bool keys_done = stage == 2;
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
     const double *eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     if (!keys_done && n <= TK_MAXK) {
-        hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, ws, h->d_sel_key,
+        hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
     } else {
         if (!keys_done)
-            hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, n, k, eig, obj, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
         hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
         hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
         int64_t chunk = (n + grid - 1) / grid;
@@ -514,20 +554,19 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;
     uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
-    const double *tie_obj = (mode == TK_MODE_COMBALL) ? h->d_obj : nullptr;
-    if (tie_obj) {
-        hipLaunchKernelGGL(tk_tilesort_kernel<true>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
-                           h->d_sel_idx, tile_key, tile_idx, tie_obj);
-        hipLaunchKernelGGL(tk_mergerank_kernel<true>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj, h->shard_rec,
-                           h->shard_rec_count, h->shard_rec_len);
-    } else {
-        hipLaunchKernelGGL(tk_tilesort_kernel<false>, dim3(ntiles), dim3(TK_THREADS), 0, h->stream, ws, h->d_sel_key,
-                           h->d_sel_idx, tile_key, tile_idx, tie_obj);
-        hipLaunchKernelGGL(tk_mergerank_kernel<false>, dim3(ntiles * TK_TILE / TK_THREADS), dim3(TK_THREADS), 0, h->stream,
-                           h->base, score_add, ws, tile_key, tile_idx, d_idx_out, d_score_out, tie_obj, h->shard_rec,
-                           h->shard_rec_count, h->shard_rec_len);
-    }
+    const double *tie_obj = (mode == TK_MODE_COMBALL || mode == TK_MODE_COMBAUTO) ? h->d_obj : nullptr;
+    const dim3 g_sort(ntiles), g_merge(ntiles * TK_TILE / TK_THREADS), blk(TK_THREADS);
+#define TK_SORT_LAUNCH(T)                                                                                                  \
+    do {                                                                                                                   \
+        hipLaunchKernelGGL(tk_tilesort_kernel<T>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key,     \
+                           tile_idx, tie_obj);                                                                             \
+        hipLaunchKernelGGL(tk_mergerank_kernel<T>, g_merge, blk, 0, h->stream, h->base, score_add, ws, tile_key, tile_idx, \
+                           d_idx_out, d_score_out, tie_obj, h->shard_rec, h->shard_rec_count, h->shard_rec_len);           \
+    } while (0)
+    if (mode == TK_MODE_COMBAUTO) TK_SORT_LAUNCH(2);
+    else if (mode == TK_MODE_COMBALL) TK_SORT_LAUNCH(1);
+    else TK_SORT_LAUNCH(0);
+#undef TK_SORT_LAUNCH
     HIP_TRY(h, hipGetLastError());
     if (d_counters_out) *d_counters_out = ws->counters;
     return 0;
@@ -537,7 +576,7 @@ int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, 
                           double *d_score_out, int64_t cnt[5])
 {
     const int64_t *d_cnt = nullptr;
-    int rc = topk_select_enqueue(h, mode, k, score_add, d_idx_out, d_score_out, &d_cnt);
+    int rc = topk_select_enqueue(h, mode, k, score_add, d_idx_out, d_score_out, &d_cnt, 0, 0);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(cnt, d_cnt, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, sdpcut_sync(h));

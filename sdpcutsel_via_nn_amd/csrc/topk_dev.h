@@ -17,10 +17,16 @@
 #ifndef TK_HREP
 #define TK_HREP 8
 #endif
+#define TK_SREP 8
 
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
-enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3, TK_MODE_COMBALL = 4 };
+// 5: combined strategy, regime resolved ON THE DEVICE by the first pass: STRONG if the score kernels
+// counted at least `sel` strong candidates (counters[5]), else COMBALL -- one selection, no host
+// round trip in either regime
+enum { TK_MODE_FEAS = 1, TK_MODE_OPT = 2, TK_MODE_STRONG = 3, TK_MODE_COMBALL = 4, TK_MODE_COMBAUTO = 5 };
+
+__device__ __forceinline__ int64_t ld_i64(const int64_t *p);
 
 struct TkState {
     uint64_t prefix;   // digits resolved so far, in place
@@ -30,8 +36,10 @@ struct TkState {
 
 struct TopkWs {
     uint32_t hist[8][TK_HREP][256];   // [pass 0..7 = digit 7..0][replica][bin]
-    int64_t counters[5];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
+    int64_t counters[8];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
                              // [4] != 0: tk_hist_rest_kernel gave up waiting, the selection is void
+                             // [5] strong candidates counted by the score kernels (TK_MODE_COMBAUTO)
+                             // [6] mode the selection ran in (copy of `mode` for the host)
     TkState state[9];        // state[p]: after p digits
     uint32_t done[8];        // ticket counters of the passes
     uint32_t blk_eq[TK_MAXBLK];
@@ -40,6 +48,8 @@ struct TopkWs {
     int64_t mode;            // TK_MODE_* of the running selection (written by its pass 0)
     uint32_t ready[9];       // tk_hist_rest_kernel: state[p] has been published inside the launch
     uint32_t pad_[1];
+    int64_t strong_rep[TK_SREP];   // strong candidates counted by the score kernels, replicated by workgroup
+                                   // (same-address device atomics are serialised, see TK_HREP)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -164,6 +174,21 @@ static __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t 
             }
         }
     }
+}
+
+__device__ __forceinline__ int64_t strong_total(const TopkWs *ws)
+{
+    int64_t t = 0;
+#pragma unroll
+    for (int r = 0; r < TK_SREP; ++r) t += ld_i64(&ws->strong_rep[r]);
+    return t;
+}
+
+// the mode a selection runs in: COMBAUTO is resolved from the strong count the score kernels left
+__device__ __forceinline__ int resolve_mode(int mode, const TopkWs *ws, int64_t sel)
+{
+    if (mode != TK_MODE_COMBAUTO) return mode;
+    return strong_total(ws) >= sel ? TK_MODE_STRONG : TK_MODE_COMBALL;
 }
 
 __device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
