@@ -104,12 +104,13 @@ __device__ __forceinline__ JacRot jacobi_angle(const double (&a)[D][D])
 {
     JacRot r;
     r.apq = a[P][Q];
-    const bool act = fabs(r.apq) > 1e-140;
     const double d = a[Q][Q] - a[P][P];
     const double b = 2.0 * r.apq;
-    const double x = act ? fma(d, d, b * b) : 1.0;
+    // (+1e-300: keeps the chain finite when a_pq and d both vanish -- then t = 0 / 1e-150 = 0, the
+    // identity rotation -- without a compare and two 64-bit selects per rotation; invisible otherwise)
+    const double x = fma(d, d, b * b) + 1e-300;
     const double den = d + copysign(jac_sqrt(x), d);
-    r.t = act ? b * jac_rcp(den) : 0.0;
+    r.t = b * jac_rcp(den);
     r.c = jac_rsqrt(fma(r.t, r.t, 1.0));
     r.s = r.t * r.c;
     return r;

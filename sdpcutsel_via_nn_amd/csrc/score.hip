@@ -158,11 +158,21 @@ __device__ __forceinline__ double tansig_lib(double n)
 //    |y| < 1.4e9 -- pre-activations of these networks stay below 1e3), which saves the
 //    double->int conversion; with the constant lowered by SHIFT the dword holds k - SHIFT, so
 //    exp(y) / 2 (SHIFT = 1, what tansig4/tansig8 want) costs nothing extra and is exact.
+// fmin() goes through the IEEE quieting rule (v_max_f64 x, x in front of the v_min_f64): the operand
+// here is an accumulator that cannot be a signalling NaN, so take the bare instruction (one issue
+// slot per activation, 150 activations per candidate)
+__device__ __forceinline__ double min_f64_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int SHIFT>
 __device__ __forceinline__ double exp_y8_scaled(double y8_in, double y8max)     // exp(8 y8_in) / 2^SHIFT
 {
     constexpr double MAGIC = 0x1.8p52 - (double)SHIFT;
-    const double y8 = fmin(y8_in, y8max);
+    const double y8 = min_f64_raw(y8_in, y8max);
     const double t = fma(y8, 11.541560327111707259, MAGIC);         // 8 log2 e
     const double k = t - MAGIC;
     const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)

@@ -94,11 +94,15 @@ class LinearRelaxation(object):
     """Minimal LP model: min c^T v, 0 <= v <= 1, rows added through
     ``self.linear_constraints.add`` exactly as the reference does on its CPLEX object.
 
-    Solved with HiGHS' dual simplex.  When SciPy's bundled HiGHS binding is importable the model
-    is kept inside the solver between solves and only the rows added since the last solve are
-    passed on, so a round re-optimises from the previous basis (what the reference gets from
-    CPLEX, cut_select_qp.py:106-110, :194); otherwise every solve starts from scratch through
-    ``scipy.optimize.linprog``."""
+    Solved with HiGHS.  When SciPy's bundled HiGHS binding is importable the model is kept inside
+    the solver between solves and only the rows added since the last solve are passed on.  Models
+    of up to ``IPM_ROWS`` rows use the dual simplex, re-optimising from the previous basis (what
+    the reference gets from CPLEX, cut_select_qp.py:106-110, :194); larger ones (spar125-075-* after
+    a round of 5000 cuts) the interior-point method with crossover to a vertex, whose time grows far
+    more slowly with the number of cuts (dual simplex: 7 / 21 / 43 s for rounds 1-3 of
+    spar125-075-1 dim 3, 360 / 630 / 780 s for rounds 3-5 at dim 4; interior point: 2 - 7 s).
+    Without the binding every solve starts from scratch through ``scipy.optimize.linprog``."""
+    IPM_ROWS = 20000
 
     def __init__(self, obj_coeffs, incremental=True):
         self.obj = np.asarray(obj_coeffs, dtype=np.float64)
@@ -137,6 +141,9 @@ class LinearRelaxation(object):
             starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
             m.addRows(r, lower, upper, int(data.shape[0]), starts, cols.astype(np.int32), data)
             self._rows_passed += r
+        big = self._rows_passed > self.IPM_ROWS
+        m.setOptionValue("solver", "ipm" if big else "simplex")
+        m.setOptionValue("run_crossover", "on")
         m.run()
         if m.getModelStatus() != core.HighsModelStatus.kOptimal:
             raise RuntimeError("HiGHS: " + m.modelStatusToString(m.getModelStatus()))

@@ -1,0 +1,182 @@
+"""BASELINE.json configs[2] at its stated size (top item): spar125-075-*, mixed-size
+covers of dimension 4 (1.7e6 candidates) and 5 (12.8e6, past the reference's 4e6 guard), the
+combined strategy with the top-10 % / 5000 cap.
+
+  * replay of a 20-round trajectory of the REAL reference (tests/golden/rounds_*.npz, produced by
+    tests/golden/make_rounds_golden.py: the reference's own selection + generation driven round after
+    round): at every recorded LP point the library must select what the reference selected;
+  * live rounds through CutSolver.cut_select_algo (device-side cover, HiGHS);
+  * one dim-5 round with the 12.8e6-candidate cover, through size-independent properties."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+PUBLISHED_COUNTS = {                     # data_tables/data_(M+S^E_{3,4,5})_opt_0.1_40.csv:99-101, column nb_subproblems
+    "spar125-075-1": {3: 133242, 4: 1700215, 5: 12845805},
+    "spar125-075-2": {3: 132145, 4: 1681784, 5: 12739984},
+    "spar125-075-3": {3: 129267, 4: 1602598, 5: 11660122},
+}
+
+
+def _instance(name):
+    from sdpcutsel_via_nn_amd import harness
+    return harness.parse_boxqp(os.path.join(GOLDEN, "instances", name + ".in"))
+
+
+@pytest.mark.parametrize("name", sorted(PUBLISHED_COUNTS))
+@pytest.mark.parametrize("dim", [3, 4, 5])
+def test_published_candidate_counts_from_the_device_enumeration(name, dim):
+    import sdpcutsel_via_nn_amd as pkg
+    inst = _instance(name)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+        assert sc.set_candidates_cover(inst["adj"], dim) == PUBLISHED_COUNTS[name][dim]
+    finally:
+        sc.close()
+
+
+def _trajectories():
+    return sorted(glob.glob(os.path.join(GOLDEN, "rounds_*.npz")))
+
+
+@pytest.mark.parametrize("path", _trajectories(), ids=[os.path.basename(p)[:-4] for p in _trajectories()])
+def test_replay_of_the_reference_trajectory(path):
+    """Every round the reference ran (its LP point, its rank-list head, its strategy switch, its number
+    of cuts): same selection from the library.  Identical selections make the next LP -- and hence the
+    whole trajectory -- identical, so this is configs[2] end to end, minus the LP solver."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi
+    g = np.load(path)
+    name, dim, sel = str(g["name"]), int(g["dim"]), int(g["sel_size"])
+    inst = _instance(name)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(dim)
+        sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+        N = sc.set_candidates_cover(inst["adj"], dim)
+        assert N == int(g["nb_subproblems"])
+        rounds = int(g["rounds_done"])
+        assert rounds >= 3
+        report = []
+        for r in range(1, rounds + 1):
+            p = "r%02d_" % r
+            strat = int(g[p + "strat"])
+            sc.set_point(g[p + "vars"])
+            res = sc.select_round(strat, sel)
+            ref_ids, ref_score = g[p + "ids"].astype(np.int64), g[p + "score"]
+            w = ref_ids.shape[0]
+            assert res["idx"].shape[0] == w and res["n_total"] == int(g[p + "list_len"]), (r, strat)
+            assert res["new_strat"] == int(g[p + "new_strat"]), (r, strat)
+            tol = 1e-9 * np.maximum(1.0, np.abs(ref_score)) + 2e-13
+            assert np.all(np.abs(res["score"] - ref_score) <= tol), (r, np.abs(res["score"] - ref_score).max())
+            same = res["idx"] == ref_ids
+            n_set = int(np.setdiff1d(res["idx"], ref_ids).size)
+            if not same.all():
+                # positions that differ must lie inside runs of equal reference scores (ties, whose order in
+                # the reference is rounding noise); ids selected by one side only must sit in the run that
+                # reaches the end of the head
+                bad = np.flatnonzero(~same)
+                for b in bad:
+                    lo, hi = b, b
+                    while lo > 0 and abs(ref_score[lo - 1] - ref_score[b]) <= tol[b]:
+                        lo -= 1
+                    while hi + 1 < w and abs(ref_score[hi + 1] - ref_score[b]) <= tol[b]:
+                        hi += 1
+                    assert hi > lo, (r, int(b))
+                    if res["idx"][b] not in ref_ids[lo:hi + 1]:
+                        assert hi == w - 1, (r, int(b))
+            nb_cuts = int((res["lam"] < -1e-15).sum())
+            assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
+            report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "
+                          "ids selected by one side only %d, cuts %d" % (name, dim, r, strat, res["new_strat"], N, w,
+                                                                        int((~same).sum()), n_set, nb_cuts))
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "r02_config3_replay.txt"), "a") as f:
+            f.write("\n".join(report) + "\n")
+    finally:
+        sc.close()
+
+
+def test_live_rounds_dim4_device_cover():
+    """Three live rounds on spar125-075-1, dim 4 (1 700 215 candidates of sizes 2..4 enumerated on the
+    device), combined strategy, 5000 cuts per round (cut_select_qp.py:37)."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd.cut_solver import DeviceAgg
+    cs = pkg.CutSolver()
+    bounds, t_total, rt, st, cuts, tri, nsub = cs.cut_select_algo(os.path.join(GOLDEN, "instances", "spar125-075-1.in"), 4, 0.1,
+                                                                  strat=4, nb_rounds_cuts=3)
+    assert nsub == 1700215 and isinstance(cs._agg_list, DeviceAgg)
+    assert cuts == [0, 5000, 5000, 5000]
+    assert bounds[0] > bounds[1] > bounds[2] > bounds[3] > 12330.0             # best known value, boxqp_instances/filenames.txt:97
+    # separation = selection + generation; the reference needs 2.5 s for 133 242 candidates (dim 3, round 1)
+    assert all(s < 0.25 for s in st[1:]), st
+    e = cs._agg_list[1700214]                                                  # records on demand, from the device
+    assert len(e[0]) in (2, 3, 4) and len(e[1]) == len(e[0]) * (len(e[0]) + 1) // 2
+
+
+@pytest.mark.parametrize("point", ["mccormick_vertex", "generic"])
+def test_dim5_round_past_the_reference_cap(oracle, point):
+    """One selection round over the dim-5 cover of spar125-075-1: 12 845 805 candidates of sizes 2..5 (the
+    reference returns at its 4e6 guard, cut_select_qp.py:117-120).  Size-independent properties: sampled
+    scores of every size class equal the oracle's, the head of every strategy is the oracle's ranking of
+    the device's scores, the fused round returns the rows of that head."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, harness
+    inst = _instance("spar125-075-1")
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(n, inst["Q_arr"])
+        assert sc.set_candidates_cover(inst["adj"], 5, max_subs=4 * 10 ** 6) == 12845805 and sc.N == 0      # the reference's guard
+        N = sc.set_candidates_cover(inst["adj"], 5)                                                        # max_subs = None
+        assert N == sc.N == 12845805
+        if point == "generic":
+            vv = harness.random_mccormick_point(n, np.random.default_rng(15))
+        else:
+            lp = harness.boxqp_relaxation(inst)
+            lp.solve()
+            vv = np.asarray(lp.get_values())
+            assert np.allclose(vv[L:], 0.5)
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.isfinite(eig).all() and np.isfinite(obj).all()
+        rng = np.random.default_rng(6)
+        pick = np.unique(np.concatenate([np.arange(4096), N - 1 - np.arange(4096), rng.choice(N, 60000, replace=False)]))
+        S, ks = sc.get_candidates(pick)
+        sizes = np.unique(ks)
+        assert set(sizes.tolist()) <= {2, 3, 4, 5} and 5 in sizes
+        for k in sizes:
+            m = ks == k
+            si = S[m, :k]
+            ref_obj = oracle.opt_score_batch(int(k), si, n, vv, inst["Q_arr"])
+            ref_eig = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][oracle.triu_positions(si, n)])
+            me = int(k) * np.abs(inst["Q_arr"][oracle.triu_positions(si, n)]).max(axis=1)
+            me[me == 0] = 1.0
+            assert np.abs(eig[pick][m] - ref_eig).max() <= 2e-13, int(k)
+            assert np.all(np.abs(obj[pick][m] - ref_obj) <= 1e-9 * np.maximum(np.abs(ref_obj), 1e-3 * me)), int(k)
+        for strat in (1, 2, 4):
+            ids, score, total, new_strat, cnt = sc.rank(strat, 5000, max_out=5000)
+            order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, 5000)
+            assert np.array_equal(ids, order[:5000]), strat
+            assert np.array_equal(score, ref_score[:5000] + 0.0) and new_strat == ref_strat and total == order.shape[0]
+        sc.set_point(vv)
+        r = sc.select_round(4, 5000)
+        order, ref_score, ref_strat, _ = oracle.rank_arrays(4, obj, eig, 5000)
+        assert np.array_equal(r["idx"], order[:5000]) and np.array_equal(r["score"], ref_score[:5000] + 0.0)
+        assert r["new_strat"] == ref_strat
+        lam, coef, rhs, cols, ks_r = sc.cut_rows(order[:5000])
+        ld = r["coef"].shape[1]
+        assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :ld]) and np.array_equal(r["rhs"], rhs)
+        assert np.array_equal(r["ks"], ks_r) and len(set(ks_r.tolist())) >= 1
+    finally:
+        sc.close()
