@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
+    ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     ap.add_argument("--k", type=int, choices=[2, 3, 4, 5], default=None, help="candidate size (default: the config's, 3)")
     ap.add_argument("--time-every", type=int, default=8,
@@ -195,6 +196,8 @@ def main():
             sc.set_option(_capi.OPT_FUSE_KEYS, 1)
         if args.no_auto_regime:
             sc.set_option(_capi.OPT_AUTO_REGIME, 0)
+        if args.no_fused_tail:
+            sc.set_option(_capi.OPT_FUSED_TAIL, 0)
         sc.set_option(_capi.OPT_KERNEL, kernel_opt)
         sc.set_network(k, *networks.load_network(k))
         Q_arr, vv, _ = synthetic.make_instance(nb_vars, seed=7)      # one LP point and one objective for the whole job

@@ -63,7 +63,11 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * kernels count the strong candidates and the selection pick its regime on the device (one selection,
  * no host round trip whether or not sel_size strong candidates exist).  0: the selection assumes the
  * common regime and the host repeats it when the count says otherwise (the round-1 behaviour). */
-enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4 };
+/* SDPCUT_OPT_FUSED_TAIL (default 1): the top-k selection runs its later passes, the count and the
+ * compaction in one launch behind bounded grid barriers instead of four launches; 0 = one launch per
+ * pass (A/B and fallback). */
+enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
+       SDPCUT_OPT_FUSED_TAIL = 5 };
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
 #define SDPCUT_MAX_K 5

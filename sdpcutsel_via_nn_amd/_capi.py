@@ -16,7 +16,7 @@ EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
 PART_STRONG = 104
 KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
-OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME = 1, 2, 3, 4
+OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL = 1, 2, 3, 4, 5
 ROW_LD = 20
 
 _c = ctypes

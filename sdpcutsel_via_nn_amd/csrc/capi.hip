@@ -183,6 +183,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_FUSE_KEYS:
         h->fuse_keys = value != 0;
         return SDPCUT_OK;
+    case SDPCUT_OPT_FUSED_TAIL:
+        h->fused_tail = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_AUTO_REGIME:
         h->auto_regime = value != 0;
         return SDPCUT_OK;

@@ -54,6 +54,7 @@ struct sdpcut_ctx {
     int kernel_variant = SDPCUT_KERNEL_MFMA;
     bool fuse_keys = false;        // SDPCUT_OPT_FUSE_KEYS (measured: no gain, see include/sdpcut.h)
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
+    bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch

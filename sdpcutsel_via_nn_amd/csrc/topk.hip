@@ -169,6 +169,245 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_
     }
 }
 
+// One-shot grid barrier `b` of a selection (its arrival counter starts at zero with the workspace).
+// Every thread's device-scope atomics are drained before the workgroup arrives.  Bounded like the
+// wait of tk_hist_rest_kernel: if the other workgroups do not show up (the GPU shared with a kernel
+// that keeps them from starting) counters[4] marks the selection void and everybody leaves.
+static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
+{
+    __shared__ int bar_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ws->bar[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        uint32_t it = 0;
+        while (ld_u32(&ws->bar[b]) < nblocks) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
+                st_i64(&ws->counters[4], 1);
+                ok = 0;
+                break;
+            }
+        }
+        bar_ok = ok;
+    }
+    __syncthreads();
+    return bar_ok != 0;
+}
+
+// Passes 1..7, the count and the compaction in ONE launch (the fast path's replacement of
+// tk_hist_kernel + tk_hist_rest_kernel + tk_count_kernel + tk_write_kernel: three launch hand-offs
+// of ~5 us each become one or two grid barriers).  After pass 1 the selection is normally closed
+// (early stop: every key >= T, at most TK_MAXK of them, in any order -- the sort that follows orders
+// them): each workgroup counts its keys >= T, reserves its slice of the output with ONE fetch-add and
+// writes.  Masses of equal keys run the remaining digits behind grid barriers and cut the last group by
+// index, which needs the per-workgroup counts of all workgroups: one more barrier.
+#define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
+__global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
+                                                               TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ int go;
+    __shared__ uint32_t red_gt[TK_THREADS], red_eq[TK_THREADS], all_gt[TK_THREADS], all_eq[TK_THREADS];
+    __shared__ uint32_t wave_cnt[TK_THREADS / 64];
+    __shared__ uint32_t c_gt, c_eq, gt_local, c_above;
+    __shared__ unsigned long long slice;
+    __shared__ uint64_t cache[TK_CACHE];
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    const bool use_cache = chunk <= TK_CACHE;      // uniform: the chunk is read from memory once
+    bool cached = false;
+    int last_pass = 0;                              // last digit pass this launch ran (its histogram is still in LDS)
+    if (threadIdx.x == 0) c_above = 0;
+    TkState st;
+    for (int p = 1;; ++p) {
+        if (p > 1) {        // state[p] is published inside this launch
+            if (threadIdx.x == 0) {
+                int ok = 1;
+                uint32_t it = 0;
+                while (ld_u32(&ws->ready[p]) == 0u) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
+                        st_i64(&ws->counters[4], 1);
+                        ok = 0;
+                        break;
+                    }
+                }
+                go = ok;
+            }
+            __syncthreads();
+            if (!go) return;
+        }
+        st.prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
+        st.need = ld_i64(&ws->state[p].need);
+        st.stop = ld_i64(&ws->state[p].stop);
+        if (st.stop || st.need < 1 || p == 8) break;      // uniform over the grid
+        hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) c_above = 0;
+        __syncthreads();
+        const int shift = 8 * (7 - p);
+        uint32_t above = 0;                               // keys of this chunk beyond the prefix' range
+        for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)TK_UNROLL * TK_THREADS) {
+            uint64_t key[TK_UNROLL];
+            bool in[TK_UNROLL];
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                in[u] = i < hi;
+                key[u] = !in[u] ? 0ull : (cached ? cache[i - lo] : keys[i]);
+            }
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                if (use_cache && !cached && in[u]) cache[i - lo] = key[u];
+                const uint64_t hi_part = key[u] >> (shift + 8), pre_part = st.prefix >> (shift + 8);
+                const bool match = in[u] && hi_part == pre_part;
+                above += in[u] && hi_part > pre_part;
+                hist_add(hist, (uint32_t)((key[u] >> shift) & 255), match);
+            }
+        }
+        cached = use_cache;
+        for (int off = 32; off > 0; off >>= 1) above += __shfl_xor((int)above, off);
+        if ((threadIdx.x & 63) == 0 && above) atomicAdd(&c_above, above);
+        __syncthreads();
+        last_pass = p;
+        finish_pass(ws, p, k, hist, gridDim.x, true);
+        __syncthreads();
+    }
+    if (st.need < 1) return;                               // empty class: n_sel stays 0
+    const uint64_t T = st.prefix;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (st.stop) {
+        // early stop: every key >= T is wanted, in any order (the sort that follows orders them)
+        uint32_t mine;
+        if (last_pass) {
+            // closed by the pass just run: this chunk's count is in its own histogram -- the keys beyond
+            // the prefix' range plus the bins from the threshold bin up -- no counting pass over the keys
+            const int shift = 8 * (7 - last_pass);
+            const uint32_t tbin = (uint32_t)((T >> shift) & 255);
+            uint32_t part = (threadIdx.x >= tbin) ? hist[threadIdx.x] : 0u;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor((int)part, off);
+            if (threadIdx.x == 0) c_gt = 0;
+            __syncthreads();
+            if (lane == 0 && part) atomicAdd(&c_gt, part);
+            __syncthreads();
+            mine = c_gt + c_above;
+        } else {
+            if (threadIdx.x == 0) c_gt = 0;
+            __syncthreads();
+            uint32_t my = 0;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) my += keys[i] >= T;
+            for (int off = 32; off > 0; off >>= 1) my += __shfl_xor((int)my, off);
+            if (lane == 0 && my) atomicAdd(&c_gt, my);
+            __syncthreads();
+            mine = c_gt;
+        }
+        if (mine == 0) return;                             // uniform per workgroup
+        if (threadIdx.x == 0) {
+            gt_local = 0;
+            slice = __hip_atomic_fetch_add((unsigned long long *)&ws->n_sel, (unsigned long long)mine, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int64_t base = (int64_t)slice;
+        for (int64_t row = lo; row < hi; row += TK_THREADS) {
+            const int64_t i = row + threadIdx.x;
+            const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : keys[i]) : 0ull;
+            const bool take = (i < hi) && key >= T;
+            const unsigned long long m = __ballot(take);
+            uint32_t wbase = 0;
+            if (lane == 0 && m) wbase = atomicAdd(&gt_local, (uint32_t)__popcll(m));
+            wbase = (uint32_t)__shfl((int)wbase, 0);
+            if (take) {
+                const int64_t slot = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                sel_key[slot] = key;
+                sel_idx[slot] = (uint32_t)i;
+            }
+        }
+        return;
+    }
+    // ---- counts of this workgroup's chunk
+    if (threadIdx.x == 0) { c_gt = 0; c_eq = 0; gt_local = 0; }
+    __syncthreads();
+    {
+        uint32_t my_gt = 0, my_eq = 0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) {
+            const uint64_t key = cached ? cache[i - lo] : keys[i];
+            my_gt += (key > T);
+            my_eq += (key == T);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            my_gt += __shfl_xor((int)my_gt, off);
+            my_eq += __shfl_xor((int)my_eq, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (my_gt) atomicAdd(&c_gt, my_gt);
+            if (my_eq) atomicAdd(&c_eq, my_eq);
+        }
+    }
+    __syncthreads();
+    // ---- exact cut at the last digit: offsets from the counts of ALL workgroups (tk_write_kernel's scheme)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&ws->blk_gt[blockIdx.x], c_gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->blk_eq[blockIdx.x], c_eq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!grid_barrier(ws, 0, gridDim.x)) return;
+    uint32_t pg = 0, pe = 0, tg = 0, te = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += TK_THREADS) {
+        const uint32_t g = ld_u32(&ws->blk_gt[b]), e = ld_u32(&ws->blk_eq[b]);
+        tg += g; te += e;
+        if (b < (int)blockIdx.x) { pg += g; pe += e; }
+    }
+    red_gt[threadIdx.x] = pg;
+    red_eq[threadIdx.x] = pe;
+    all_gt[threadIdx.x] = tg;
+    all_eq[threadIdx.x] = te;
+    __syncthreads();
+    for (int off = TK_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            red_gt[threadIdx.x] += red_gt[threadIdx.x + off]; red_eq[threadIdx.x] += red_eq[threadIdx.x + off];
+            all_gt[threadIdx.x] += all_gt[threadIdx.x + off]; all_eq[threadIdx.x] += all_eq[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    const int64_t base_gt = red_gt[0];
+    int64_t base_eq = red_eq[0];
+    const int64_t greater = all_gt[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        st_i64(&ws->n_sel, greater + (st.need < (int64_t)all_eq[0] ? st.need : (int64_t)all_eq[0]));
+    const bool want_gt = c_gt != 0;
+    const bool want_eq = c_eq != 0 && base_eq < st.need;
+    if (!want_gt && !want_eq) return;     // uniform
+    for (int64_t row = lo; row < hi; row += TK_THREADS) {
+        const int64_t i = row + threadIdx.x;
+        const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : keys[i]) : 0ull;
+        if (i < hi && key > T) {
+            const int64_t slot = base_gt + atomicAdd(&gt_local, 1u);
+            sel_key[slot] = key;
+            sel_idx[slot] = (uint32_t)i;
+        }
+        if (want_eq) {     // uniform
+            const bool is_eq = (i < hi) && (key == T);
+            const unsigned long long m = __ballot(is_eq);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t row_total = 0;
+            for (int w = 0; w < TK_THREADS / 64; ++w) {
+                if (w < wave) before += wave_cnt[w];
+                row_total += wave_cnt[w];
+            }
+            const int64_t rank = base_eq + before;
+            if (is_eq && rank < st.need) {
+                sel_key[greater + rank] = T;
+                sel_idx[greater + rank] = (uint32_t)i;
+            }
+            base_eq += row_total;
+            __syncthreads();
+        }
+    }
+}
+
 // threshold known: per block (contiguous chunk of the index space) count the keys above it and
 // the keys equal to it -- no global atomics, the write pass derives its offsets from these
 __global__ __launch_bounds__(TK_THREADS) void tk_count_kernel(int64_t n, int64_t chunk, const uint64_t *keys, TopkWs *ws)
@@ -543,13 +782,18 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     } else {
         if (!keys_done)
             hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
-        hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
-        hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
         int64_t chunk = (n + grid - 1) / grid;
         chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
-        hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
-        hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
-                           h->d_sel_key, h->d_sel_idx);
+        if (h->fused_tail) {
+            hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+                               h->d_sel_key, h->d_sel_idx);
+        } else {
+            hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
+                               h->d_sel_key, h->d_sel_idx);
+        }
     }
     const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
     uint64_t *tile_key = h->d_sel_key + TK_MAXK;

@@ -50,6 +50,7 @@ struct TopkWs {
     uint32_t pad_[1];
     int64_t strong_rep[TK_SREP];   // strong candidates counted by the score kernels, replicated by workgroup
                                    // (same-address device atomics are serialised, see TK_HREP)
+    uint32_t bar[8];               // one-shot grid barriers of the fused kernels (arrival counters)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
