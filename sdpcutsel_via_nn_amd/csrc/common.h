@@ -200,6 +200,7 @@ int topk_begin(sdpcut_ctx *h, void **ws, uint64_t **keys);
 int64_t *topk_strong_counter(void *ws);      // TopkWs::strong_rep (TK_SREP = 8 replicas) of a workspace handed out by topk_begin
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[5]);
+int topk_select_keys_on_device(sdpcut_ctx *h, int64_t n, int64_t k, int64_t *d_idx_out, double *d_val_out, int64_t cnt[5]);
 void free_topk_ws(sdpcut_ctx *h);
 // the workspace NOT used by the selection enqueued last, and its size in 8-byte words: a later
 // kernel of the same stream may zero it and then set h->topk_alt_clean (saves the next memset)

@@ -176,7 +176,8 @@ int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     const int64_t n = h->N;
     if (sel_size > n) sel_size = n;
     if (score_add) *score_add = 0.0;
-    if (!(n > 0 && max_out >= 1 && max_out <= 8192)) return 0;
+    if (!(n > 0 && max_out >= 1 && max_out <= 16384)) return 0;      // TK_MAXK (topk_dev.h)
+    if (max_out > 8192 && (strat == SDPCUT_STRAT_COMB || h->shard_rec)) return 0;     // big heads: plain rankings only
     if (strat == SDPCUT_STRAT_FEAS) return 1;
     if (strat == SDPCUT_STRAT_OPT) return 2;
     if (strat == SDPCUT_PART_STRONG) return 3;
@@ -264,7 +265,7 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     // then a function of its own (obj_improve, eigmin) alone (cut_select_qp.py:606-623), and the head
     // of the re-sorted list is a top-k by (new score, obj_improve, index) -- radix select again, with
     // obj_improve as secondary key where new scores tie (second stable sort of :625).
-    if (strat == SDPCUT_STRAT_COMB && strong >= 0 && strong < sel_size && n > 0 && max_out >= 1 && max_out <= 8192) {
+    if (strat == SDPCUT_STRAT_COMB && strong >= 0 && strong < sel_size && n > 0 && max_out >= 1 && max_out <= 16384) {
         const int64_t *d_c4 = nullptr;
         rc = topk_select_enqueue(h, 4 /* TK_MODE_COMBALL */, max_out, 0.0, d_idx_out, d_score_out, &d_c4);
         if (rc) return rc;

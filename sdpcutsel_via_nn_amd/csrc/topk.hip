@@ -634,8 +634,8 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
                                                                   int64_t *idx_out, double *score_out, const double *obj,
                                                                   int64_t *rec_hdr, int64_t rec_count, int64_t rec_len)
 {
-    __shared__ uint64_t sk[TK_MAXK];
-    __shared__ uint32_t si[TK_MAXK];
+    __shared__ uint64_t sk[TK_LDSK];
+    __shared__ uint32_t si[TK_LDSK];
     if (rec_hdr) {
         // shard record (shard.hip): this launch also writes the 8-word header in front of the head
         // and pads the slots behind the entries it emits with (-inf, INT64_MAX); rec_len >= 0 is the
@@ -655,6 +655,72 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_kernel(int64_t base, 
     } else {
         mergerank_body<false>(base, score_add, ws, tile_key, tile_idx, idx_out, score_out, obj, sk, si);
     }
+}
+
+// Heads of 8193 .. 16384 entries: the composite (key, index) pairs of all tiles no longer fit LDS, the
+// keys alone do (128 KB); an index is fetched from the tile array only where two keys are equal.
+// raw: score_out receives the key's low 63 bits as a double (keys that are not score images: the
+// triangle inequalities' (density, violation) composite).
+template <bool TIE>
+__global__ __launch_bounds__(TK_THREADS) void tk_mergerank_big_kernel(int64_t base, double score_add, const TopkWs *ws,
+                                                                      const uint64_t *tile_key, const uint32_t *tile_idx,
+                                                                      int64_t *idx_out, double *score_out, const double *obj,
+                                                                      int raw, int64_t emit_limit)
+{
+    __shared__ uint64_t sk[TK_MAXK];
+    const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
+    if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
+    const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
+    for (int j = threadIdx.x; j < ntiles * TK_TILE; j += TK_THREADS) sk[j] = tile_key[j];
+    __syncthreads();
+    const int e = blockIdx.x * TK_THREADS + threadIdx.x;
+    if (e >= ntiles * TK_TILE) return;
+    const uint64_t ke = sk[e];
+    const uint32_t ie = tile_idx[e];
+    if (ie == 0xffffffffu && ke == ~0ull) return;             // padding
+    const int te = e / TK_TILE;
+    int rank = e - te * TK_TILE;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t == te) continue;
+        int lo = 0, hi = TK_TILE;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint64_t km = sk[t * TK_TILE + mid];
+            bool less = km < ke;
+            if (km == ke) less = comp_less<TIE>(km, tile_idx[t * TK_TILE + mid], ke, ie, obj);
+            lo = less ? mid + 1 : lo;
+            hi = less ? hi : mid;
+        }
+        rank += lo;
+    }
+    if (rank >= k_eff || rank >= emit_limit) return;
+    idx_out[rank] = base + (int64_t)ie;
+    score_out[rank] = raw ? __longlong_as_double((long long)(~ke & 0x7fffffffffffffffull)) : score_of(~ke) + score_add;
+}
+
+// pass 0 over keys that already exist (key 0 = not in the class): leading-digit histogram and class size
+__global__ __launch_bounds__(TK_THREADS) void tk_prekeys_kernel(int64_t n, int64_t k, const uint64_t *keys, TopkWs *ws)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cnt;
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    uint32_t c_class = 0;
+    const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
+    const int64_t rounds = (n + stride - 1) / stride;
+    for (int64_t r = 0; r < rounds; ++r) {          // every lane runs every round: hist_add is wave-cooperative
+        const int64_t i = r * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+        const bool in = i < n;
+        const uint64_t key = in ? keys[i] : 0ull;
+        c_class += in && key != 0ull;
+        hist_add(hist, (uint32_t)(key >> 56), in);
+    }
+    if (c_class) atomicAdd(&cnt, c_class);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd((unsigned long long *)&ws->counters[0], (unsigned long long)cnt);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st_i64(&ws->mode, TK_MODE_FEAS); st_i64(&ws->counters[6], TK_MODE_FEAS); }
+    finish_pass(ws, 0, k, hist, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -756,6 +822,64 @@ __global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t 
     }
 }
 
+// Everything behind pass 0: the remaining digit passes, the compaction, the sort and the ranks.
+// n keys in h->d_key_a; k <= TK_MAXK; raw: see tk_mergerank_big_kernel (heads > TK_LDSK only).
+static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t n, int64_t k, double score_add,
+                                    int64_t *d_idx_out, double *d_score_out, bool compacted, int raw, int64_t base,
+                                    int64_t emit_limit = TK_MAXK)
+{
+    int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
+    const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
+    if (!compacted) {
+        int64_t chunk = (n + grid - 1) / grid;
+        chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
+        if (h->fused_tail) {
+            hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+                               h->d_sel_key, h->d_sel_idx);
+        } else {
+            hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
+            hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
+                               h->d_sel_key, h->d_sel_idx);
+        }
+    }
+    const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;    // an early stop compacts up to maxk entries; idle tiles exit at once
+    const int ntiles = (int)(maxk / TK_TILE);
+    uint64_t *tile_key = h->d_sel_key + TK_MAXK;
+    uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
+    const double *tie_obj = (mode == TK_MODE_COMBALL || mode == TK_MODE_COMBAUTO) ? h->d_obj : nullptr;
+    const dim3 g_sort(ntiles), g_merge(ntiles * TK_TILE / TK_THREADS), blk(TK_THREADS);
+    if (maxk > TK_LDSK) {
+        // big heads (8193 .. 16384): keys-only merge; the device-resolved regime never asks for them
+        if (mode == TK_MODE_COMBAUTO || h->shard_rec) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: head too long for this mode");
+        if (tie_obj) {
+            hipLaunchKernelGGL(tk_tilesort_kernel<1>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key, tile_idx, tie_obj);
+            hipLaunchKernelGGL(tk_mergerank_big_kernel<true>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,
+                               d_idx_out, d_score_out, tie_obj, raw, emit_limit);
+        } else {
+            hipLaunchKernelGGL(tk_tilesort_kernel<0>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key, tile_idx, tie_obj);
+            hipLaunchKernelGGL(tk_mergerank_big_kernel<false>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,
+                               d_idx_out, d_score_out, tie_obj, raw, emit_limit);
+        }
+    } else {
+        if (raw) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: raw output needs the big-head merge");
+#define TK_SORT_LAUNCH(T)                                                                                                  \
+    do {                                                                                                                   \
+        hipLaunchKernelGGL(tk_tilesort_kernel<T>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key,     \
+                           tile_idx, tie_obj);                                                                             \
+        hipLaunchKernelGGL(tk_mergerank_kernel<T>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,    \
+                           d_idx_out, d_score_out, tie_obj, h->shard_rec, h->shard_rec_count, h->shard_rec_len);           \
+    } while (0)
+        if (mode == TK_MODE_COMBAUTO) TK_SORT_LAUNCH(2);
+        else if (mode == TK_MODE_COMBALL) TK_SORT_LAUNCH(1);
+        else TK_SORT_LAUNCH(0);
+#undef TK_SORT_LAUNCH
+    }
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
 // stage 0: fresh selection; 1: the workspace has been handed out by topk_begin already (the score
 // kernels left their strong count in it); 2: the score kernels also ran pass 0 (keys, leading digit,
 // class counters).  mode TK_MODE_COMBAUTO: resolved by the first pass against `sel` (stage 1 only).
@@ -776,43 +900,37 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
-    if (!keys_done && n <= TK_MAXK) {
+    const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
+    const bool small = !keys_done && n <= maxk;
+    if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
-    } else {
-        if (!keys_done)
-            hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
-        int64_t chunk = (n + grid - 1) / grid;
-        chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
-        if (h->fused_tail) {
-            hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                               h->d_sel_key, h->d_sel_idx);
-        } else {
-            hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
-            hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
-            hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
-            hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
-                               h->d_sel_key, h->d_sel_idx);
-        }
+    } else if (!keys_done) {
+        hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
     }
-    const int ntiles = TK_MAXK / TK_TILE;      // an early stop compacts up to TK_MAXK entries; idle tiles exit at once
-    uint64_t *tile_key = h->d_sel_key + TK_MAXK;
-    uint32_t *tile_idx = h->d_sel_idx + TK_MAXK;
-    const double *tie_obj = (mode == TK_MODE_COMBALL || mode == TK_MODE_COMBAUTO) ? h->d_obj : nullptr;
-    const dim3 g_sort(ntiles), g_merge(ntiles * TK_TILE / TK_THREADS), blk(TK_THREADS);
-#define TK_SORT_LAUNCH(T)                                                                                                  \
-    do {                                                                                                                   \
-        hipLaunchKernelGGL(tk_tilesort_kernel<T>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key,     \
-                           tile_idx, tie_obj);                                                                             \
-        hipLaunchKernelGGL(tk_mergerank_kernel<T>, g_merge, blk, 0, h->stream, h->base, score_add, ws, tile_key, tile_idx, \
-                           d_idx_out, d_score_out, tie_obj, h->shard_rec, h->shard_rec_count, h->shard_rec_len);           \
-    } while (0)
-    if (mode == TK_MODE_COMBAUTO) TK_SORT_LAUNCH(2);
-    else if (mode == TK_MODE_COMBALL) TK_SORT_LAUNCH(1);
-    else TK_SORT_LAUNCH(0);
-#undef TK_SORT_LAUNCH
-    HIP_TRY(h, hipGetLastError());
+    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base);
+    if (rc) return rc;
     if (d_counters_out) *d_counters_out = ws->counters;
+    return 0;
+}
+
+// Head of a ranking over n PRECOMPUTED keys in h->d_key_a (0 = not in the class), ties by index:
+// idx_out = entry index, val_out = the key's low 63 bits as a double; cnt as in topk_select_on_device.
+int topk_select_keys_on_device(sdpcut_ctx *h, int64_t n, int64_t k, int64_t *d_idx_out, double *d_val_out, int64_t cnt[5])
+{
+    if (k < 1 || k > TK_MAXK || n < 1 || n > h->ws_n) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k / n out of range");
+    int rc = topk_begin(h, nullptr, nullptr);
+    if (rc) return rc;
+    TopkWs *ws = (TopkWs *)h->d_topk_ws;
+    int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
+    const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
+    // (always through the big-head merge: it is the one with the raw key output)
+    const int64_t kk = k <= TK_LDSK ? TK_LDSK + 1 : k;
+    hipLaunchKernelGGL(tk_prekeys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, kk, h->d_key_a, ws);
+    rc = topk_enqueue_after_pass0(h, ws, TK_MODE_FEAS, n, kk, 0.0, d_idx_out, d_val_out, false, 1, 0, k);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(cnt, ws->counters, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
     return 0;
 }
 

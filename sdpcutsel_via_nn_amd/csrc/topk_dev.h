@@ -9,7 +9,8 @@
 
 #define TK_THREADS 256
 #define TK_MAXBLK 256
-#define TK_MAXK 8192
+#define TK_LDSK 8192     // heads whose compacted superset (keys AND indices) fits the merge kernel's LDS
+#define TK_MAXK 16384    // largest head: the merge keeps the keys in LDS and reads indices only on ties
 #define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
 // Replicas of the global histogram: same-address device-scope atomics are serialised at ~15-20 ns
 // each, so 256 workgroups flushing into ONE row cost ~5 us per pass; block b adds into replica
@@ -119,13 +120,14 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
             // where ties are cut by index as before.
             const int64_t k_eff = ld_i64(&ws->counters[3]);
             const int64_t in_bin = here - above;
+            const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;     // what the sort buffers of this head hold
             const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
             // Mode COMBALL cannot cut a group of equal keys by index (their order is by obj_improve):
             // at the last digit it either takes the whole group too, or declares the selection void
             // (counters[4]) and the host sorts the full list.
             const bool comball = ld_i64(&ws->mode) == TK_MODE_COMBALL;
-            if (p == 7 && comball && in_bin > need - above && superset > TK_MAXK) st_i64(&ws->counters[4], 2);
-            if ((p < 7 || comball) && superset <= TK_MAXK) {
+            if (p == 7 && comball && in_bin > need - above && superset > maxk) st_i64(&ws->counters[4], 2);
+            if ((p < 7 || comball) && superset <= maxk) {
                 for (int qq = p + 1; qq <= 8; ++qq) {
                     st_i64((int64_t *)&ws->state[qq].prefix, (int64_t)pre);
                     st_i64(&ws->state[qq].need, in_bin);   // every key equal to the bin's lowest value, if any

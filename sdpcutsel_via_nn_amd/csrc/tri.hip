@@ -1,10 +1,10 @@
 // Triangle-inequality separation (SURVEY.md section 8 f, row 3; reference
 // cut_select_qp.py:799-863).  Per round every retained triple i1<i2<i3 yields four
 // violations; the violated ones (>= 1e-7) are ranked by (density desc, violation desc), ties
-// in entry order 4*triple + type (Python's stable sort), and the head is returned.
+// in entry order 4*triple + type (Python's stable sort), and the head is returned.  The caller
+// consumes at most 10 000 of the ~1e6 entries (_TRI_CUTS_PER_ROUND_MAX): the head comes from the
+// radix select of topk.hip over the composite keys, not from a sort of all of them.
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -40,15 +40,6 @@ __global__ __launch_bounds__(256) void tri_viol_kernel(int64_t T, const int32_t 
     }
     for (int off = 32; off > 0; off >>= 1) nviol += __shfl_xor(nviol, off);
     if ((threadIdx.x & 63) == 0 && nviol) atomicAdd((unsigned long long *)&counters[0], (unsigned long long)nviol);
-}
-
-__global__ void tri_emit_kernel(int64_t count, const uint64_t *key, const uint32_t *val, int64_t *entry_out,
-                                double *viol_out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    entry_out[i] = (int64_t)val[i];
-    viol_out[i] = __longlong_as_double((long long)(key[i] & 0x7fffffffffffffffull));
 }
 
 int tri_preprocess(sdpcut_ctx *h, const uint8_t *adjacency, int64_t *n_triples)
@@ -87,7 +78,8 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
                  int64_t *n_written)
 {
     const int64_t T = h->n_tri, E = 4 * T;
-    int64_t cnt = 0;
+    int64_t cnt[5] = {0, 0, 0, 0, 0};
+    if (max_out > 16384) return sdpcut_fail(h, SDPCUT_EINVAL, "tri_separate: at most 16384 entries (the reference takes <= 10000)");
     if (E > 0) {
         int rc = ensure_rank_ws(h, E);
         if (rc) return rc;
@@ -95,19 +87,18 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
         HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 8 * sizeof(int64_t), h->stream));
         hipLaunchKernelGGL(tri_viol_kernel, dim3((int)((T + 255) / 256)), dim3(256), 0, h->stream, T, h->d_tri,
                            h->d_tri_dense3, h->d_vars, h->nb_vars, h->L, h->d_key_a, h->d_val_a, h->d_counters);
-        size_t tb = h->tmp_bytes;
-        HIP_TRY(h, rocprim::radix_sort_pairs_desc(h->d_tmp, tb, h->d_key_a, h->d_key_b, h->d_val_a, h->d_val_b,
-                                                  (size_t)E, 0, 64, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(&cnt, h->d_counters, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, sdpcut_sync(h));
-    }
-    const int64_t w = cnt < max_out ? cnt : max_out;
-    if (w > 0) {
-        hipLaunchKernelGGL(tri_emit_kernel, dim3((int)((w + 255) / 256)), dim3(256), 0, h->stream, w, h->d_key_b,
-                           h->d_val_b, d_entry_out, d_viol_out);
         HIP_TRY(h, hipGetLastError());
+        if (max_out > 0) {
+            rc = topk_select_keys_on_device(h, E, max_out, d_entry_out, d_viol_out, cnt);
+            if (rc) return rc;
+            if (cnt[4]) return sdpcut_fail(h, SDPCUT_EHIP, "tri_separate: selection gave up (GPU shared with a blocking kernel)");
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(cnt, h->d_counters, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, sdpcut_sync(h));
+        }
     }
-    if (n_violated) *n_violated = cnt;
+    const int64_t w = cnt[0] < max_out ? cnt[0] : max_out;
+    if (n_violated) *n_violated = cnt[0];
     if (n_written) *n_written = w;
     return 0;
 }

@@ -601,9 +601,10 @@ def test_topk_select_path_equals_full_sort_full_size(full_c2, scorer, strat):
         if strat == 4:
             assert cnt["strong"] == full[4]["strong"] and cnt["violated"] == full[4]["violated"]
     if strat != 4:
-        for k in (8191, 8192):
+        # 8193 .. 16384: the keys-only merge (tk_mergerank_big_kernel); beyond: the full sort
+        for k in (8191, 8192, 8193, 10000, 16384, 16385):
             ids, score, _, _, _ = scorer.rank(strat, sel, max_out=k)
-            assert np.array_equal(ids, full[0][:k]) and np.array_equal(score, full[1][:k])
+            assert np.array_equal(ids, full[0][:k]) and np.array_equal(score, full[1][:k]), (strat, k)
 
 
 @pytest.mark.parametrize("distinct_vars", [0, 1, 12])
@@ -628,8 +629,8 @@ def test_topk_select_with_masses_of_equal_keys_full_size(full_c2, scorer, oracle
         values, counts = np.unique(eig, return_counts=True)
         assert counts.max() > 8192 * 2 and (eig < -1e-15).all()
         for strat in (1, 2, 4):
-            for sel, k in ((5000, 5000), (5000, 77), (8192, 8192)):
-                if strat == 4 and k > sel:
+            for sel, k in ((5000, 5000), (5000, 77), (8192, 8192), (12000, 12000)):
+                if strat == 4 and (k > sel or k > 8192):
                     continue
                 ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=k)
                 order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, sel)
