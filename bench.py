@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
+    ap.add_argument("--coop", action="store_true", help="A/B: cooperative launch of the fused selection kernel (+20 us per round)")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     ap.add_argument("--k", type=int, choices=[2, 3, 4, 5], default=None, help="candidate size (default: the config's, 3)")
     ap.add_argument("--time-every", type=int, default=8,
@@ -198,6 +199,8 @@ def main():
             sc.set_option(_capi.OPT_AUTO_REGIME, 0)
         if args.no_fused_tail:
             sc.set_option(_capi.OPT_FUSED_TAIL, 0)
+        if args.coop:
+            sc.set_option(_capi.OPT_COOP_LAUNCH, 1)
         sc.set_option(_capi.OPT_KERNEL, kernel_opt)
         sc.set_network(k, *networks.load_network(k))
         Q_arr, vv, _ = synthetic.make_instance(nb_vars, seed=7)      # one LP point and one objective for the whole job
@@ -303,6 +306,7 @@ def main():
             "roofline": roofline(K, n_local, k_ms, traffic),
         }
         out["roofline"]["kernel_ms_samples"] = len(kernel_ms)
+        out["config"]["selection_fallbacks"] = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)       # rounds answered by the full-sort path
         out["roofline"]["traffic_source"] = ("profiles/score_kernel_traffic.json (rocprofv3 --pmc passes of this kernel at "
                                              "this size; not re-measured in this run)") if traffic else None
         if world == 1 and args.config == "c2" and not args.no_secondary:

@@ -66,8 +66,21 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
 /* SDPCUT_OPT_FUSED_TAIL (default 1): the top-k selection runs its later passes, the count and the
  * compaction in one launch behind bounded grid barriers instead of four launches; 0 = one launch per
  * pass (A/B and fallback). */
+/* SDPCUT_OPT_COOP_LAUNCH (default 0): make that launch a cooperative one (hipLaunchCooperativeKernel), so
+ * that the runtime guarantees the co-residency its grid barriers rely on.  Measured on MI355X: +20 us per
+ * round (0.455 instead of 0.435 ms).  Without it the grid is capped at one workgroup per CU (256 x 256
+ * threads, 38 KB of LDS each), which an otherwise idle device always holds, and every wait is bounded: a
+ * barrier that does not complete within a few milliseconds voids the selection and the full-sort path
+ * answers (counted by SDPCUT_STAT_SELECT_FALLBACKS). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
-       SDPCUT_OPT_FUSED_TAIL = 5 };
+       SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6 };
+
+/* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
+ * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier
+ * timed out because other work kept its workgroups from starting, or a tie group overflowed the sort
+ * buffers) and were answered by the full-sort path instead -- same result, ~1 ms instead of ~0.1 ms. */
+enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2 };
+int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value);
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
 #define SDPCUT_MAX_K 5

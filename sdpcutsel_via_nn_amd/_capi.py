@@ -16,7 +16,8 @@ EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
 PART_STRONG = 104
 KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
-OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL = 1, 2, 3, 4, 5
+OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL, OPT_COOP_LAUNCH = 1, 2, 3, 4, 5, 6
+STAT_ROUNDS, STAT_SELECT_FALLBACKS = 1, 2
 ROW_LD = 20
 
 _c = ctypes
@@ -34,6 +35,7 @@ SIGNATURES = {
     "sdpcut_destroy": [_vp],
     "sdpcut_set_option": [_vp, _c.c_int, _c.c_int64],
     "sdpcut_set_stream": [_vp, _vp],
+    "sdpcut_get_stat": [_vp, _c.c_int, _i64p],
     "sdpcut_synchronize": [_vp],
     "sdpcut_set_network": [_vp, _c.c_int, _c.c_int, _i32p, _dp, _c.c_int64],
     "sdpcut_set_instance": [_vp, _c.c_int32, _dp],
@@ -178,6 +180,11 @@ class Scorer(object):
         None restores the handle's own stream."""
         arg = _vp(-1 & 0xFFFFFFFFFFFFFFFF) if stream_ptr is None else (_vp(stream_ptr) if stream_ptr else None)
         self._check(self._lib.sdpcut_set_stream(self._h, arg))
+
+    def get_stat(self, which):
+        v = _c.c_int64(0)
+        self._check(self._lib.sdpcut_get_stat(self._h, int(which), ctypes.byref(v)))
+        return int(v.value)
 
     def synchronize(self):
         self._check(self._lib.sdpcut_synchronize(self._h))

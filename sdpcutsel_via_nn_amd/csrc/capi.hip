@@ -183,6 +183,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_FUSE_KEYS:
         h->fuse_keys = value != 0;
         return SDPCUT_OK;
+    case SDPCUT_OPT_COOP_LAUNCH:
+        h->coop_launch = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_FUSED_TAIL:
         h->fused_tail = value != 0;
         return SDPCUT_OK;
@@ -194,6 +197,16 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         return SDPCUT_OK;
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown option");
+}
+
+int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value)
+{
+    if (!h || !value) return SDPCUT_EINVAL;
+    switch (which) {
+    case SDPCUT_STAT_ROUNDS: *value = h->stat_rounds; return SDPCUT_OK;
+    case SDPCUT_STAT_SELECT_FALLBACKS: *value = h->stat_fallbacks; return SDPCUT_OK;
+    }
+    return sdpcut_fail(h, SDPCUT_EINVAL, "unknown statistic");
 }
 
 int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
@@ -709,6 +722,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         if (rc) return rc;
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
     }
+    ++h->stat_rounds;
+    if (fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
     if (!have) {
         // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
         // (the fast attempt above already counted the strong candidates: no second attempt)

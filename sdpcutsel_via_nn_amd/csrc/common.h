@@ -55,6 +55,8 @@ struct sdpcut_ctx {
     bool fuse_keys = false;        // SDPCUT_OPT_FUSE_KEYS (measured: no gain, see include/sdpcut.h)
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
+    bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)
+    int64_t stat_rounds = 0, stat_fallbacks = 0;   // sdpcut_get_stat
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
 // resident together on the 256 CUs, and the wait is bounded anyway: when the flag does not come
 // (the GPU shared with a kernel that keeps blocks of this grid from starting) counters[4] is raised,
 // every block leaves, and the host falls back to the full-sort path.
-#define TK_SPIN_LIMIT (1 << 20)
+#define TK_SPIN_LIMIT (1 << 16)      // x s_sleep: a few milliseconds; a legitimate wait is tens of microseconds
 __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_t n, int64_t k, const uint64_t *keys,
                                                                   TopkWs *ws)
 {
@@ -834,8 +834,19 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
         int64_t chunk = (n + grid - 1) / grid;
         chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
         if (h->fused_tail) {
-            hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                               h->d_sel_key, h->d_sel_idx);
+            // cooperative launch: the runtime guarantees that all workgroups of the grid are resident
+            // together, which is what the kernel's grid barriers need (256 workgroups of 256 threads on
+            // 256 CUs); its waits stay bounded anyway
+            const uint64_t *keys_arg = h->d_key_a;
+            uint64_t *sk_arg = h->d_sel_key;
+            uint32_t *si_arg = h->d_sel_idx;
+            int64_t n_arg = n, k_arg = k, chunk_arg = chunk;
+            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg};
+            if (h->coop_launch)
+                HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
+            else
+                hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+                                   h->d_sel_key, h->d_sel_idx);
         } else {
             hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
             hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
