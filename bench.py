@@ -113,6 +113,21 @@ def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
     return out
 
 
+class _StdoutToStderr(object):
+    """fd-level redirect: native libraries (RCCL prints a version banner when its first communicator
+    comes up) must not put lines on stdout, which carries exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def roofline(k, n_per_launch, kernel_ms, traffic):
     tflops = FLOPS_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e12
     gbs = BYTES_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -171,17 +186,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or solo_dist
-    if use_dist:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
     import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if use_dist:
-        dist.barrier()
+    with _StdoutToStderr():
+        if use_dist:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
+        if rank == 0:
+            entry.build()
+        if use_dist:
+            dist.barrier()          # the first collective: the communicator (and RCCL's banner) come up here
 
     from sdpcutsel_via_nn_amd import _capi, networks, synthetic
     from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector

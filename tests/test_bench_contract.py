@@ -73,3 +73,21 @@ def test_bench_config_c4_shard():
     assert abs(d["value"] - 12_500_000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["value"] > 5e8
     assert d["roofline"]["candidates_per_launch"] == 12_500_000 and 0.2 < d["roofline"]["frac"] < 1.0
     assert d["cpu_baseline"]["value"] > 1e4
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_real_rccl_prints_one_json_line():
+    """The driver's N > 1 launch form (torch.distributed.run, one rank per GPU) with one rank: the
+    process group is RCCL, the collectives of the sharded round are issued for real
+    (SDPCUT_FORCE_COLLECTIVES=1), and stdout still carries exactly one JSON line (RCCL's version
+    banner goes to stderr)."""
+    env = dict(os.environ, SDPCUT_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and 5e8 < d["value"] < 1e10
