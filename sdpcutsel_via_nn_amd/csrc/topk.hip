@@ -109,7 +109,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
 // Passes p0..7 in ONE launch.  Normally the selection was closed after one or two digits and every
 // block returns at once (one empty launch instead of six).  Otherwise (masses of equal keys) the
 // blocks run the remaining passes separated by a grid barrier: the block that resolves digit p
-// publishes ready[p+1], the others wait for it.  All TK_MAXBLK (<= 512) blocks of 256 threads are
+// publishes ready[p+1], the others wait for it.  All TK_MAXBLK (= 256) blocks of 256 threads are
 // resident together on the 256 CUs, and the wait is bounded anyway: when the flag does not come
 // (the GPU shared with a kernel that keeps blocks of this grid from starting) counters[4] is raised,
 // every block leaves, and the host falls back to the full-sort path.
