@@ -38,8 +38,8 @@ FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only
 BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
 HBM_PEAK_GBS = 8000.0
-KERNEL_NAMES = {2: "score_mfma_kernel<2, 64, 3, false>", 3: "score_mfma_kernel<3, 50, 3, false>",
-                4: "score_mfma_kernel<4, 50, 3, false>", 5: "score_mfma_kernel<5, 64, 4, false>"}
+KERNEL_NAMES = {2: "score_mfma_kernel<2, 64, 3, false, false>", 3: "score_mfma_kernel<3, 50, 3, false, false>",
+                4: "score_mfma_kernel<4, 50, 3, false, false>", 5: "score_mfma_kernel<5, 64, 4, false, false>"}
 CONFIGS = {
     "c2": dict(nb_vars=100, k=3, total=None, per_gpu=10 ** 6, scaling="weak",
                text="configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, eig + neural_net_3D "

@@ -1,5 +1,6 @@
 // extern "C" surface of libsdpcut_hip.so (declared in include/sdpcut.h).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 
@@ -355,6 +356,23 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
     d.wtail = nh_.d_blob + o_wtail;
     for (int l = 0; l < n_layers; ++l) { d.raw_w[l] = nh_.d_blob + o_rw[l]; d.raw_b[l] = nh_.d_blob + o_rb[l]; }
     d.ymin = ymin; d.b_out = B[nh][0]; d.y_ymin = y_ymin; d.y_gain = y_gain; d.y_xoffset = y_xoffset;
+    {
+        // bound of every hidden pre-activation: |n_j| <= sum_i |W_ji| max|in_i| + |b_j| with |in| <= SDPCUT_INPUT_CLAMP
+        // for the mapped inputs (x in [0,1], |q| <= 1/k map into [-1,1]) and <= 1 behind a tansig.  The tansig4 path
+        // needs -2n <= 176, the tail rows -2n <= 704; 80 leaves a factor of two.
+        double worst = 0.0;
+        int fan = d_in;
+        for (int l = 0; l < nh; ++l) {
+            const double in_max = l == 0 ? SDPCUT_INPUT_CLAMP : 1.0;
+            for (int j = 0; j < H; ++j) {
+                double acc = std::fabs(B[l][j]);
+                for (int i = 0; i < fan; ++i) acc += std::fabs(W[l][(size_t)j * fan + i]) * in_max;
+                worst = acc > worst ? acc : worst;
+            }
+            fan = H;
+        }
+        d.unclamped_ok = worst < 40.0 ? 1 : 0;      // |n| < 40  <=>  -2n < 80
+    }
     nh_.set = true;
     return SDPCUT_OK;
 }

@@ -33,7 +33,12 @@ struct NetDev {
     const double *raw_w[MAX_LAYERS]; // row-major [out][in] (simple kernel)
     const double *raw_b[MAX_LAYERS];
     double ymin, b_out, y_ymin, y_gain, y_xoffset;
+    // every pre-activation is provably below the tansig's overflow clamp when the mapped inputs lie in
+    // [-SDPCUT_INPUT_CLAMP, SDPCUT_INPUT_CLAMP] (sdpcut_set_network): the MFMA kernel then clamps the 9..20
+    // inputs of a candidate once instead of its 150..256 activations
+    int unclamped_ok;
 };
+#define SDPCUT_INPUT_CLAMP 3.0
 
 struct Bucket {
     int64_t n = 0;

@@ -168,11 +168,20 @@ __device__ __forceinline__ double min_f64_raw(double a, double b)
     return r;
 }
 
-template <int SHIFT>
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// CLAMP = false: the caller guarantees y8_in <= y8max (NetDev::unclamped_ok: the network's
+// pre-activations are bounded, see sdpcut_set_network) -- one instruction less per activation.
+template <int SHIFT, bool CLAMP = true>
 __device__ __forceinline__ double exp_y8_scaled(double y8_in, double y8max)     // exp(8 y8_in) / 2^SHIFT
 {
     constexpr double MAGIC = 0x1.8p52 - (double)SHIFT;
-    const double y8 = min_f64_raw(y8_in, y8max);
+    const double y8 = CLAMP ? min_f64_raw(y8_in, y8max) : y8_in;
     const double t = fma(y8, 11.541560327111707259, MAGIC);         // 8 log2 e
     const double k = t - MAGIC;
     const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)
@@ -206,9 +215,10 @@ __device__ __forceinline__ double tansig(double n)
     return fma(2.0, q, -1.0);
 }
 
+template <bool CLAMP = true>
 __device__ __forceinline__ double tansig_y8(double y8)  // the accumulators of the MFMA kernel hold y/8 = -n/4 (NetDev::bias_q)
 {
-    const double d = exp_y8(y8, 88.0) + 1.0;
+    const double d = exp_y8_scaled<0, CLAMP>(y8, 88.0) + 1.0;
     double q = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, q, 1.0);
     q = fma(q, fma(e, e, e), q);
@@ -217,9 +227,10 @@ __device__ __forceinline__ double tansig_y8(double y8)  // the accumulators of t
 
 // HALF the denominator of tansig, h = (exp(-2n) + 1) / 2, so that tansig = 1/h - 1 (the factor 2
 // of the formula is absorbed exactly by the exponent shift of exp_y8_scaled<1>).
+template <bool CLAMP = true>
 __device__ __forceinline__ double tansig_hden_y8(double y8, double y8max)
 {
-    return exp_y8_scaled<1>(y8, y8max) + 0.5;
+    return exp_y8_scaled<1, CLAMP>(y8, y8max) + 0.5;
 }
 
 // Four tansig values with ONE reciprocal: 1/h_i = (1 / (h0 h1 h2 h3)) * prod_{j != i} h_j.
@@ -232,10 +243,11 @@ __device__ __forceinline__ double tansig_hden_y8(double y8, double y8max)
 // candidate's score does not depend on its neighbours in the wave.  (Sharing over the eight
 // values of the two column tiles saved another 0.7 % but made duplicates of a candidate differ
 // in the last bit depending on their position -- ties would no longer break by index.)
+template <bool CLAMP = true>
 __device__ __forceinline__ void tansig4(double &v0, double &v1, double &v2, double &v3)
 {
-    const double d0 = tansig_hden_y8(v0, 22.0), d1 = tansig_hden_y8(v1, 22.0);
-    const double d2 = tansig_hden_y8(v2, 22.0), d3 = tansig_hden_y8(v3, 22.0);
+    const double d0 = tansig_hden_y8<CLAMP>(v0, 22.0), d1 = tansig_hden_y8<CLAMP>(v1, 22.0);
+    const double d2 = tansig_hden_y8<CLAMP>(v2, 22.0), d3 = tansig_hden_y8<CLAMP>(v3, 22.0);
     const double d01 = d0 * d1, d23 = d2 * d3;
     const double dd = d01 * d23;
     double q = __builtin_amdgcn_rcp(dd);
@@ -249,12 +261,12 @@ __device__ __forceinline__ void tansig4(double &v0, double &v1, double &v2, doub
 }
 
 // tansig of one MFMA C/D fragment (rows 16 t + 4 r + q, r = 0..3); rows >= H are padding -> 0
-template <int H>
+template <int H, bool CLAMP = true>
 __device__ __forceinline__ d4 tansig_tile(d4 c, int t)
 {
     double v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
 #ifndef SDPCUT_ABL_NOTANSIG     // tools/build_ablation.sh: timing experiments only
-    tansig4(v0, v1, v2, v3);
+    tansig4<CLAMP>(v0, v1, v2, v3);
 #endif
     d4 out;
     out[0] = (16 * t + 0 < H) ? v0 : 0.0;
@@ -283,7 +295,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // Both column tiles of a pass share ONE tansig evaluation: after the two xor-adds every lane of a
 // column holds the full sums, so lanes q = 0, 1 take tile j = 0 and lanes q = 2, 3 tile j = 1
 // (neuron u = q & 1); a final xor-32 shuffle hands the j = 1 values to lanes q = 0, 1.
-template <int NT>
+template <int NT, bool CLAMP = true>
 __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], const double *bias, int q, d4 &out0,
                                            d4 &out1)
 {
@@ -298,7 +310,7 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
             v += __shfl_xor(v, 32);
             pre = (q == 2 * j + u) ? v + bias[u] : pre;
         }
-    const double t = tansig_y8(pre);
+    const double t = tansig_y8<CLAMP>(pre);
     const double t1 = __shfl_xor(t, 32);
     out0 = d4{0.0, 0.0, 0.0, 0.0};
     out1 = d4{0.0, 0.0, 0.0, 0.0};
@@ -376,7 +388,9 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 // ------------------------------------------------------------------------------------------
 // MFMA kernel.  K candidate size, H hidden width, NH hidden layers; FUSE: also run the first pass
 // of the top-k selection (ScoreArgs::tk).
-template <int K, int H, int NH, bool FUSE = false>
+// CLAMP = false (NetDev::unclamped_ok): the tansig clamps are dropped and the staged inputs are
+// clamped to [-3, 3] instead (inactive for every x in [0, 1], |q| <= 1/k, see sdpcut_set_network).
+template <int K, int H, int NH, bool FUSE = false, bool CLAMP = true>
 __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 {
     constexpr int M = K * (K + 1) / 2;
@@ -490,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             if (i < DIN) {
                 const double v = (i < K) ? cd.x[i < K ? i : 0] : cd.q[i >= K ? i - K : 0];
                 xp = (v - net.inmap[i]) * net.inmap[DIN + i] + net.ymin;
+                if constexpr (!CLAMP) xp = min_f64_raw(max_f64_raw(xp, -SDPCUT_INPUT_CLAMP), SDPCUT_INPUT_CLAMP);
             }
             feat[wave][i][lane] = xp;
         }
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bin[s][j], cur[t][j], 0, 0, 0);
                 }
 #pragma unroll
-                for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H>(cur[t][j], t);
+                for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H, CLAMP>(cur[t][j], t);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (NT > 0) {
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                         for (int j = 0; j < J; ++j) ts[j][u] = fma(bin[s][j], w, ts[j][u]);
                     }
-                tail_rows2<NT>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                tail_rows2<NT, CLAMP>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
             }
             wf += T * S0 * 64;
             // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
@@ -580,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H>(cur[t][j], t);
+                    for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H, CLAMP>(cur[t][j], t);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (NT > 0) {
@@ -597,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                             for (int j = 0; j < J; ++j) ts[j][u] = fma(prev[s / 4][j][s % 4], w, ts[j][u]);
                         }
-                    tail_rows2<NT>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                    tail_rows2<NT, CLAMP>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
                 }
                 wf += T * SH * 64;
             }
@@ -1218,6 +1233,11 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
             if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
             if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true>), grid, 256);
             if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, true>), grid, 256);
+        } else if (A.net.unclamped_ok) {
+            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, false, false>), grid, 256);
+            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, false, false>), grid, 256);
+            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, false, false>), grid, 256);
+            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, false, false>), grid, 256);
         } else {
             if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3>), grid, 256);
             if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3>), grid, 256);
