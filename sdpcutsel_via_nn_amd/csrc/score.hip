@@ -213,6 +213,31 @@ __device__ __forceinline__ double exp_y8_scaled(double y8_in, double y8max)     
     p = p * p;
     return ldexp(p, __double2loint(t));
 }
+
+// exp(8 y8) / 2^SHIFT + addend for BOUNDED arguments (|8 y8| <= 80, NetDev::unclamped_ok): the power of two goes
+// into the exponent field of p^4 with one integer add -- p^4 lies in [0.65, 1.47] and |k| <= 117, so the field
+// neither overflows nor reaches the denormals -- and the last squaring, the scaling and the addend become ONE
+// fma: 14 instead of 16 issue slots per activation, one rounding less.
+template <int SHIFT>
+__device__ __forceinline__ double exp_y8_plus_bounded(double y8, double addend)
+{
+    constexpr double MAGIC = 0x1.8p52 - (double)SHIFT;
+    const double t = fma(y8, 11.541560327111707259, MAGIC);         // 8 log2 e; low dword = k - SHIFT
+    const double k = t - MAGIC;
+    const double r = fma(k, -0x1.62e42fefa39efp-4, y8);              // fl(ln2 / 8)
+    double p = 0x1.a02041015378fp-13;
+    p = fma(p, r, 0x1.6c1d00cea5bf1p-10);
+    p = fma(p, r, 0x1.111111080fc42p-7);
+    p = fma(p, r, 0x1.5555554653263p-5);
+    p = fma(p, r, 0x1.5555555555689p-3);
+    p = fma(p, r, 0x1.0000000000171p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    p = p * p;
+    p = p * p;                                                       // exp(r)^4
+    const double ps = __hiloint2double(__double2hiint(p) + (__double2loint(t) << 20), __double2loint(p));
+    return fma(ps, p, addend);
+}
 __device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(8 y8_in), y8_in = -n / 4
 {
     return exp_y8_scaled<0>(y8_in, y8max);
@@ -233,7 +258,7 @@ __device__ __forceinline__ double tansig(double n)
 template <bool CLAMP = true>
 __device__ __forceinline__ double tansig_y8(double y8)  // the accumulators of the MFMA kernel hold y/8 = -n/4 (NetDev::bias_q)
 {
-    const double d = exp_y8_scaled<0, CLAMP>(y8, 88.0) + 1.0;
+    const double d = CLAMP ? exp_y8_scaled<0, true>(y8, 88.0) + 1.0 : exp_y8_plus_bounded<0>(y8, 1.0);
     double q = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, q, 1.0);
     q = fma(q, fma(e, e, e), q);
@@ -245,7 +270,8 @@ __device__ __forceinline__ double tansig_y8(double y8)  // the accumulators of t
 template <bool CLAMP = true>
 __device__ __forceinline__ double tansig_hden_y8(double y8, double y8max)
 {
-    return exp_y8_scaled<1, CLAMP>(y8, y8max) + 0.5;
+    if constexpr (CLAMP) return exp_y8_scaled<1, true>(y8, y8max) + 0.5;
+    else return exp_y8_plus_bounded<1>(y8, 0.5);
 }
 
 // Four tansig values with ONE reciprocal: 1/h_i = (1 / (h0 h1 h2 h3)) * prod_{j != i} h_j.
@@ -1243,7 +1269,12 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         // the workgroups that are resident together (2 per CU), each looping over its tiles, so that the
         // flush is paid once per resident workgroup, in the kernel's ragged tail.
         const int grid = grid_for(h, ntiles, A.tk ? SDPCUT_FUSE_BLOCKS_PER_CU : SDPCUT_MFMA_BLOCKS_PER_CU);
-        if (A.tk) {
+        if (A.tk && A.net.unclamped_ok) {      // (same arithmetic as the unfused kernel of the same network: bit-equal scores)
+            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true, false>), grid, 256);
+            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true, false>), grid, 256);
+            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true, false>), grid, 256);
+            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, true, false>), grid, 256);
+        } else if (A.tk) {
             if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true>), grid, 256);
             if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
             if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true>), grid, 256);
