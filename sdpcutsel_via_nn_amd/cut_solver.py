@@ -675,11 +675,12 @@ class CutSolver(GpuCutSelectionMixin):
     _CONVERGENCE_TOL = 10 ** (-3)         # cut_select_qp.py:29
 
     def cut_select_algo(self, filename, dim, sel_size, strat=2, nb_rounds_cuts=20, term_on=False,
-                        triangle_on=False, strong_only=False, max_subs=_THRES_MAX_SUBS):
+                        triangle_on=False, strong_only=False, max_subs=_THRES_MAX_SUBS, on_round=None):
         """Cutting-plane rounds on a BoxQP ``.in`` file, same arguments and default return tuple as
         the reference's entry point (cut_select_qp.py:73-221), with HiGHS as LP solver, the native
         cover enumeration and the GPU selection / generation / triangle separation in between.
-        ``max_subs=None`` lifts the reference's 4e6 candidate guard (:117-120).  Dense cuts
+        ``max_subs=None`` lifts the reference's 4e6 candidate guard (:117-120); ``on_round(r, log)`` is
+        called after every LP solve (progress of long runs).  Dense cuts
         (strat 0), exact-SDP strategies and chordal extensions are out of scope.
         -> (bound per solve, total s, round s, separation s, PSD cuts per round, triangle cuts per
         round, number of candidates)."""
@@ -722,7 +723,7 @@ class CutSolver(GpuCutSelectionMixin):
             return {"sdp": sdp, "tri": tri}
 
         log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts, setup_s=t_model,
-                                     stop_tol=self._CONVERGENCE_TOL if term_on else None)
+                                     stop_tol=self._CONVERGENCE_TOL if term_on else None, on_round=on_round)
         sep = [t_model] + log.separation_s
         return ([-v for v in log.bounds], clock() - t_start, [a + b for a, b in zip(log.solve_s, [0.0] + log.separation_s)],
                 sep, [0] + log.column("sdp"), log.column("tri"), n_cand)

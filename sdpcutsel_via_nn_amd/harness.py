@@ -265,10 +265,11 @@ class RoundLog(object):
         return len(b) >= 3 and b[-1] != b[0] and (b[-1] - b[-2]) / (b[-1] - b[0]) < tol
 
 
-def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=None):
+def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=None, on_round=None):
     """Drive ``max_rounds`` rounds on ``lp`` (anything with solve / get_values /
     get_objective_value): ``separate(round_no, point) -> dict of counts`` appends cuts to the LP
     between two solves.  ``setup_s`` is added to the first solve's time (model building).
+    ``on_round(round_no, log)`` is called after every solve (progress of long runs).
     -> RoundLog."""
     from timeit import default_timer
     clock = clock or default_timer
@@ -283,6 +284,8 @@ def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=N
 
     point = solve()
     log.solve_s[0] += setup_s
+    if on_round:
+        on_round(0, log)
     for round_no in range(1, max_rounds + 1):
         if stop_tol is not None and log.stalled(stop_tol):
             break
@@ -290,6 +293,8 @@ def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=N
         log.counts.append(separate(round_no, point))
         log.separation_s.append(clock() - t)
         point = solve()
+        if on_round:
+            on_round(round_no, log)
     return log
 
 

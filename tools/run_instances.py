@@ -22,8 +22,17 @@ SOL = {"spar020-100-1": 706.5, "spar040-030-1": 839.5, "spar125-075-1": 12330.0,
 def run(name, dim, strat, rounds, triangle=False, term_on=False):
     cs = pkg.CutSolver()
     t = time.time()
+
+    def progress(r, log):       # long runs: one line per solve, so that a run cut short still leaves its rounds behind
+        if rounds > 6:
+            c = log.counts[-1] if log.counts else {}
+            print("      %s dim %d round %2d: bound %.4f gap %.4f, %s cuts, separation %.4f s, LP %.2f s" % (
+                name, dim, r, -log.bounds[-1], (log.bounds[-1] - log.bounds[0]) / (-SOL[name] - log.bounds[0]), c.get("sdp", 0),
+                log.separation_s[-1] if log.separation_s else 0.0, log.solve_s[-1]), flush=True)
+
     bounds, t_total, rt, st, cuts, tri, nsub = cs.cut_select_algo(os.path.join(G, name + ".in"), dim, 0.1, strat=strat,
-                                                                  nb_rounds_cuts=rounds, triangle_on=triangle, term_on=term_on)
+                                                                  nb_rounds_cuts=rounds, triangle_on=triangle, term_on=term_on,
+                                                                  on_round=progress)
     gaps = [(bounds[0] - b) / (bounds[0] - SOL[name]) for b in bounds]
     print("%s dim %d strat %d%s: N=%d, %d rounds, total %.1f s (separation %.3f s, LP + model %.1f s)"
           % (name, dim, strat, " +tri" if triangle else "", nsub, len(cuts) - 1, time.time() - t, sum(st[1:]),
