@@ -144,3 +144,41 @@ def test_sel_size_edge_cases(oracle, golden_boxqp):
     s_big, rl_big = oracle.sel_eigcut_by_ordering_on_measure(agg, L, 4, vv, sel_size=10 ** 6)
     assert len(rl_big) == len(agg) and s_big in (1, 4)
     assert oracle.sel_eigcut_by_ordering_on_measure([], L, 1, vv) == []
+
+
+# ----------------------------------------------------------------------------- configs[2] trajectories
+def _trajectory_files():
+    import glob
+    return sorted(glob.glob(os.path.join(GOLDEN, "rounds_*.npz")))
+
+
+@pytest.mark.parametrize("path", _trajectory_files(), ids=[os.path.basename(p)[:-4] for p in _trajectory_files()])
+def test_oracle_reproduces_reference_trajectory_rounds(oracle, path):
+    """The oracle against the REAL reference at BASELINE configs[2] scale (1.7e6 candidates of sizes 2..4):
+    at recorded LP points of the 20-round trajectory (tests/golden/make_rounds_golden.py) the oracle's
+    array ranking gives the reference's rank-list head -- ids, scores, strategy switch -- for the first
+    round (McCormick vertex), the round of the strategy switch and a late round."""
+    from sdpcutsel_via_nn_amd import _capi, harness
+    g = np.load(path)
+    name, dim, sel = str(g["name"]), int(g["dim"]), int(g["sel_size"])
+    inst = harness.parse_boxqp(os.path.join(GOLDEN, "instances", name + ".in"))
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    S, ks, N = _capi.enumerate_cover(inst["adj"], dim)
+    assert N == int(g["nb_subproblems"])
+    rounds = int(g["rounds_done"])
+    switch = next((r for r in range(1, rounds + 1) if int(g["r%02d_new_strat" % r]) != int(g["r%02d_strat" % r])), 2)
+    for r in sorted({1, switch, min(rounds, 12)}):
+        p = "r%02d_" % r
+        vv, strat = g[p + "vars"], int(g[p + "strat"])
+        obj, lam = np.zeros(N), np.zeros(N)
+        for k in np.unique(ks):
+            m = np.nonzero(ks == k)[0]
+            si = S[m, :k]
+            obj[m] = oracle.opt_score_batch(int(k), si, n, vv, inst["Q_arr"])
+            lam[m] = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][oracle.triu_positions(si, n)])
+        order, score, new_strat, _ = oracle.rank_arrays(strat, obj, lam, sel)
+        ref_ids, ref_score = g[p + "ids"].astype(np.int64), g[p + "score"]
+        w = ref_ids.shape[0]
+        assert order.shape[0] == int(g[p + "list_len"]) and new_strat == int(g[p + "new_strat"]), (r, strat)
+        assert np.array_equal(score[:w], ref_score), (r, strat)              # bit-exact scores
+        assert np.array_equal(order[:w], ref_ids), (r, strat)                # identical selection
