@@ -725,10 +725,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
     // results directly into the pinned host block (no copy engine); one synchronisation
     const int64_t *d_cnt = nullptr;
-    h->sort_deferred = false;
-    h->defer_sort = !h->coop_launch;        // sort, ranks and rows in one launch (round_finish_kernel)
     rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, stage, auto_regime);
-    h->defer_sort = false;
     if (rc < 0) return rc;
     const bool fast_tried = rc == 1;
     if (fast_tried) {
@@ -737,8 +734,7 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         // host polls that word instead of waiting for the runtime's completion signal (~5 us earlier)
         int64_t *hdr = (int64_t *)h->pinned;
         const int64_t serial = ++h->round_serial;
-        rc = h->sort_deferred ? launch_round_finish(h, cap, d_idx, d_sc, coef_ld, h->pinned_dev, serial)
-                              : launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
+        rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
         if (rc) return rc;
         rc = wait_round_done(h, hdr + 7, serial);
         if (rc) return rc;

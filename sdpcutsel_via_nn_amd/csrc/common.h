@@ -119,13 +119,6 @@ struct sdpcut_ctx {
     void *point_stage = nullptr, *point_stage_dev = nullptr;
     size_t point_stage_bytes = 0;
     bool point_inflight = false;   // a transfer out of point_stage may still be running
-    // fused round: the selection leaves its sort to the epilogue launch (round_finish_kernel, score.hip)
-    bool defer_sort = false;       // in: the caller can take the sort over
-    bool sort_deferred = false;    // out: it has been left to the caller, described by the fields below
-    void *ps_ws = nullptr;
-    const double *ps_obj = nullptr;
-    int ps_tie = 0;                // 0 plain, 1 obj_improve tie key, 2 decided by the device-resolved mode
-    double ps_score_add = 0.0;
     int64_t round_serial = 0;      // completion word of the fused round (round_rows_kernel -> pinned header)
     uint32_t *d_done_ticket = nullptr;
 };
@@ -172,9 +165,6 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
 // written to `block` (device view of the pinned host block; layout of sdpcut_select_round_view).
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
                       int coef_ld, void *block, int64_t hdr_bytes = 64, int64_t done_serial = 0);
-// sort + merge ranks + rows of the head in ONE launch (needs h->sort_deferred from the selection just enqueued)
-int launch_round_finish(sdpcut_ctx *h, int64_t cap, int64_t *d_idx, double *d_score, int coef_ld, void *block,
-                        int64_t done_serial);
 int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n);
 int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial);   // capi.hip
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,

@@ -1133,100 +1133,6 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
     }
 }
 
-// The whole tail of a fused round behind the compaction, in ONE launch of 32 workgroups: tile sort ->
-// grid barrier -> merge ranks -> grid barrier -> rows of the head + results into the host block +
-// completion word (tk_tilesort_kernel + tk_mergerank_kernel + round_rows_kernel: three launch
-// hand-offs of ~5 us become two barriers of ~2 us).  Data handed between workgroups inside the launch
-// (sorted tiles, ranked ids / scores) moves through device-scope atomic stores and loads.
-struct FinishArgs {
-    TopkWs *ws;
-    const uint64_t *sel_key; const uint32_t *sel_idx;
-    uint64_t *tile_key; uint32_t *tile_idx;
-    const double *obj;
-    int64_t base; double score_add; int tie;
-    int64_t *idx; double *score;            // device staging of the ranked head
-    int64_t cap, n_local; const int32_t *set5, *ks; const double *vars; int32_t nv; int64_t L; int coef_ld;
-    char *block; uint64_t *zero_ptr; int zero_words; int64_t done_serial; uint32_t *done_ticket;
-};
-
-__global__ __launch_bounds__(TK_THREADS) void round_finish_kernel(FinishArgs a)
-{
-    __shared__ __align__(16) unsigned char smem[TK_LDSK * 12];       // 96 KB: (keys | indices) of all tiles, later the row tile
-    uint64_t *sk = (uint64_t *)smem;
-    uint32_t *si = (uint32_t *)(smem + (size_t)TK_LDSK * 8);
-    const int t = threadIdx.x;
-    for (int w = blockIdx.x * TK_THREADS + t; w < a.zero_words; w += gridDim.x * TK_THREADS) a.zero_ptr[w] = 0ull;
-    const bool tie = a.tie == 1 || (a.tie == 2 && a.ws->mode == TK_MODE_COMBALL);
-    bool ok = true;
-    if (tie) tilesort_body<true, true>(a.ws, a.sel_key, a.sel_idx, a.tile_key, a.tile_idx, a.obj, sk, si);
-    else tilesort_body<false, true>(a.ws, a.sel_key, a.sel_idx, a.tile_key, a.tile_idx, a.obj, sk, si);
-    ok = grid_barrier(a.ws, 1, gridDim.x);
-    if (ok) {
-        // (device-resolved regime: BIG_M belongs to the strong class only, not to COMBALL's own scores)
-        if (tie) mergerank_body<true, true>(a.base, a.tie == 2 ? 0.0 : a.score_add, a.ws, a.tile_key, a.tile_idx, a.idx, a.score, a.obj, sk, si);
-        else mergerank_body<false, true>(a.base, a.score_add, a.ws, a.tile_key, a.tile_idx, a.idx, a.score, a.obj, sk, si);
-        ok = grid_barrier(a.ws, 2, gridDim.x);
-    }
-    // ---- rows of the head, straight into the host block (layout of sdpcut_select_round_view)
-    const int64_t cap = a.cap;
-    int64_t *o_c4 = (int64_t *)a.block;
-    int64_t *o_idx = (int64_t *)(a.block + 64);
-    double *o_score = (double *)(o_idx + cap);
-    double *o_lam = o_score + cap;
-    double *o_rhs = o_lam + cap;
-    double *o_coef = o_rhs + cap;
-    int32_t *o_ks = (int32_t *)(o_coef + cap * a.coef_ld);
-    if (blockIdx.x == 0 && t < 7) o_c4[t] = ld_i64(&a.ws->counters[t]);     // counters, strong count, mode; [4] != 0: void
-    int64_t limit = ok ? a.ws->counters[3] : 0;
-    if (limit > cap) limit = cap;
-    double *tile = (double *)smem;                                            // [256][coef_ld]
-    const int64_t first = (int64_t)blockIdx.x * TK_THREADS;
-    const int64_t i = first + t;
-    if (i < limit) {
-        const int64_t gid = ld_x<true>(&a.idx[i]);
-        const int64_t c = gid - a.base;
-        double co[SDPCUT_ROW_LD];
-        int64_t cl[SDPCUT_ROW_LD];
-#pragma unroll
-        for (int m = 0; m < SDPCUT_ROW_LD; ++m) co[m] = 0.0;
-        double lam = __builtin_nan(""), rhs = 0.0;
-        int k = 0;
-        if (c >= 0 && c < a.n_local) {
-            k = a.ks[c];
-            const int32_t *s5 = a.set5 + c * 5;
-            switch (k) {
-            case 2: cut_row_one<2>(s5, a.vars, a.nv, a.L, &lam, co, &rhs, cl); break;
-            case 3: cut_row_one<3>(s5, a.vars, a.nv, a.L, &lam, co, &rhs, cl); break;
-            case 4: cut_row_one<4>(s5, a.vars, a.nv, a.L, &lam, co, &rhs, cl); break;
-            default: cut_row_one<5>(s5, a.vars, a.nv, a.L, &lam, co, &rhs, cl); break;
-            }
-        }
-        o_idx[i] = gid;
-        o_score[i] = ld_x<true>(&a.score[i]);
-        o_lam[i] = lam;
-        o_rhs[i] = rhs;
-        o_ks[i] = k;
-#pragma unroll
-        for (int m = 0; m < SDPCUT_ROW_LD; ++m)
-            if (m < a.coef_ld) tile[t * a.coef_ld + m] = co[m];
-    }
-    __syncthreads();
-    const int64_t nlive = (limit - first < TK_THREADS) ? limit - first : TK_THREADS;
-    const int total = nlive > 0 ? (int)nlive * a.coef_ld : 0;
-    for (int w = t; w < total; w += TK_THREADS) o_coef[first * a.coef_ld + w] = tile[w];
-    // completion word for the polling host (see round_rows_kernel)
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) {
-        const uint32_t tk = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == gridDim.x - 1) {
-            __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            __hip_atomic_store(o_c4 + 7, a.done_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
 // LP point: mapped host memory -> device table (sdpcut_set_point)
 __global__ __launch_bounds__(256) void point_copy_kernel(const double *src, double *dst, int64_t n)
 {
@@ -1442,35 +1348,6 @@ int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n)
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(point_copy_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, h->stream, src_mapped, h->d_vars, n);
     HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int launch_round_finish(sdpcut_ctx *h, int64_t cap, int64_t *d_idx, double *d_score, int coef_ld, void *block,
-                        int64_t done_serial)
-{
-    if (!h->sort_deferred || cap <= 0 || cap > TK_LDSK) return sdpcut_fail(h, SDPCUT_ESTATE, "round finish: no deferred sort");
-    if (!h->d_done_ticket) {
-        HIP_TRY(h, hipMalloc((void **)&h->d_done_ticket, 64));
-        HIP_TRY(h, hipMemsetAsync(h->d_done_ticket, 0, 64, h->stream));
-    }
-    uint64_t *zp = nullptr;
-    int zw = 0;
-    int rc = topk_alt_ws(h, &zp, &zw);
-    if (rc) return rc;
-    FinishArgs a;
-    a.ws = (TopkWs *)h->ps_ws;
-    a.sel_key = h->d_sel_key; a.sel_idx = h->d_sel_idx;
-    a.tile_key = h->d_sel_key + TK_MAXK; a.tile_idx = h->d_sel_idx + TK_MAXK;
-    a.obj = h->ps_obj;
-    a.base = h->base; a.score_add = h->ps_score_add; a.tie = h->ps_tie;
-    a.idx = d_idx; a.score = d_score;
-    a.cap = cap; a.n_local = h->N; a.set5 = h->d_set_orig; a.ks = h->d_k; a.vars = h->d_vars; a.nv = h->nb_vars; a.L = h->L;
-    a.coef_ld = coef_ld;
-    a.block = (char *)block; a.zero_ptr = zp; a.zero_words = zw; a.done_serial = done_serial; a.done_ticket = h->d_done_ticket;
-    hipLaunchKernelGGL(round_finish_kernel, dim3(TK_LDSK / TK_THREADS), dim3(TK_THREADS), 0, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
-    h->topk_alt_clean = true;
-    h->sort_deferred = false;
     return 0;
 }
 

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
 // resident together on the 256 CUs, and the wait is bounded anyway: when the flag does not come
 // (the GPU shared with a kernel that keeps blocks of this grid from starting) counters[4] is raised,
 // every block leaves, and the host falls back to the full-sort path.
+#define TK_SPIN_LIMIT (1 << 16)      // x s_sleep: a few milliseconds; a legitimate wait is tens of microseconds
 __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_t n, int64_t k, const uint64_t *keys,
                                                                   TopkWs *ws)
 {
@@ -168,6 +169,33 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_
     }
 }
 
+// One-shot grid barrier `b` of a selection (its arrival counter starts at zero with the workspace).
+// Every thread's device-scope atomics are drained before the workgroup arrives.  Bounded like the
+// wait of tk_hist_rest_kernel: if the other workgroups do not show up (the GPU shared with a kernel
+// that keeps them from starting) counters[4] marks the selection void and everybody leaves.
+static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
+{
+    __shared__ int bar_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ws->bar[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        uint32_t it = 0;
+        while (ld_u32(&ws->bar[b]) < nblocks) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
+                st_i64(&ws->counters[4], 1);
+                ok = 0;
+                break;
+            }
+        }
+        bar_ok = ok;
+    }
+    __syncthreads();
+    return bar_ok != 0;
+}
+
 // Passes 1..7, the count and the compaction in ONE launch (the fast path's replacement of
 // tk_hist_kernel + tk_hist_rest_kernel + tk_count_kernel + tk_write_kernel: three launch hand-offs
 // of ~5 us each become one or two grid barriers).  After pass 1 the selection is normally closed
@@ -175,15 +203,9 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_
 // them): each workgroup counts its keys >= T, reserves its slice of the output with ONE fetch-add and
 // writes.  Masses of equal keys run the remaining digits behind grid barriers and cut the last group by
 // index, which needs the per-workgroup counts of all workgroups: one more barrier.
-//
-// PASS0 (the fast path of a fused round): pass 0 -- keys from the scores, leading-digit histogram, class
-// counters, tk_keys_kernel's work -- runs in the same launch in front of a first grid barrier; a chunk
-// that fits the LDS cache never writes its keys to memory at all.
 #define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
-template <bool PASS0>
-__global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, uint64_t *keys,
-                                                               TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx, int mode,
-                                                               int64_t sel, const double *eig, const double *obj)
+__global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
+                                                               TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx)
 {
     __shared__ uint32_t hist[256];
     __shared__ int go;
@@ -197,55 +219,9 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     bool cached = false;
     int last_pass = 0;                              // last digit pass this launch ran (its histogram is still in LDS)
     if (threadIdx.x == 0) c_above = 0;
-    if constexpr (PASS0) {
-        __shared__ uint32_t cnt0[3];
-        mode = resolve_mode(mode, ws, sel);         // uniform over the grid: the strong count is final before this launch
-        hist[threadIdx.x] = 0;
-        if (threadIdx.x < 3) cnt0[threadIdx.x] = 0;
-        __syncthreads();
-        uint32_t c_class = 0, c_viol = 0, c_pos = 0;
-        for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)TK_UNROLL * TK_THREADS) {
-            double e[TK_UNROLL], o[TK_UNROLL];
-            bool in[TK_UNROLL];
-#pragma unroll
-            for (int u = 0; u < TK_UNROLL; ++u) {
-                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
-                in[u] = i < hi;
-                e[u] = (in[u] && eig) ? eig[i] : 0.0;
-                o[u] = (in[u] && obj) ? obj[i] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < TK_UNROLL; ++u) {
-                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
-                uint64_t key = 0;
-                if (in[u]) {
-                    key = masked_key(mode, e[u], o[u]);
-                    if (use_cache) cache[i - lo] = key; else keys[i] = key;
-                    c_class += (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? 1u : (key != 0ull);
-                    c_viol += (eig != nullptr) && (e[u] < SDPCUT_NEG_EIGVAL);
-                    c_pos += (obj != nullptr) && (o[u] > 0.0);
-                }
-                hist_add(hist, (uint32_t)(key >> 56), in[u]);
-            }
-        }
-        cached = use_cache;
-        if (c_class) atomicAdd(&cnt0[0], c_class);
-        if (c_viol) atomicAdd(&cnt0[1], c_viol);
-        if (c_pos) atomicAdd(&cnt0[2], c_pos);
-        __syncthreads();
-        if (threadIdx.x < 3 && cnt0[threadIdx.x])
-            atomicAdd((unsigned long long *)&ws->counters[threadIdx.x], (unsigned long long)cnt0[threadIdx.x]);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            st_i64(&ws->mode, mode);
-            st_i64(&ws->counters[6], mode);
-            st_i64(&ws->counters[5], strong_total(ws));
-        }
-        finish_pass(ws, 0, k, hist, gridDim.x, true);      // the last workgroup resolves the digit and publishes ready[1]
-        __syncthreads();
-    }
     TkState st;
     for (int p = 1;; ++p) {
-        if (PASS0 || p > 1) {        // state[p] is published inside this launch
+        if (p > 1) {        // state[p] is published inside this launch
             if (threadIdx.x == 0) {
                 int ok = 1;
                 uint32_t it = 0;
@@ -530,6 +506,63 @@ __global__ __launch_bounds__(TK_THREADS) void tk_write_kernel(int64_t n, int64_t
 //      of entries preceding it in every other tile (binary searches over tiles staged in LDS;
 //      composites are unique, so ranks are a permutation).
 // ~k log k work instead of the k^2 of a counting sort, two short launches.
+#define TK_TILE 512
+
+// obj != NULL (mode COMBALL): equal keys are ordered by obj_improve descending before the index --
+// the first stable sort of the reference (:601) under its second one (:625).  The scores are only
+// fetched for equal keys (rare unless the point is degenerate); padding never reaches the fetch.
+// The sort kernels are instantiated twice: TIE = false is the plain composite compare (a memory
+// fetch and a branch inside the comparator cost the common modes 30 % of both kernels).
+template <bool TIE>
+__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, const double *obj)
+{
+    if constexpr (!TIE) {
+        return ka < kb || (ka == kb && ia < ib);
+    } else {
+        if (ka != kb) return ka < kb;
+        if (ia != 0xffffffffu && ib != 0xffffffffu) {
+            const uint64_t oa = key_of(obj[ia]), ob = key_of(obj[ib]);
+            if (oa != ob) return oa > ob;
+        }
+        return ia < ib;
+    }
+}
+
+template <bool TIE>
+__device__ __forceinline__ void tilesort_body(const TopkWs *ws, const uint64_t *sel_key, const uint32_t *sel_idx,
+                                              uint64_t *tile_key, uint32_t *tile_idx, const double *obj, uint64_t *sk,
+                                              uint32_t *si)
+{
+    const int k_eff = (int)ws->n_sel;              // compacted entries (a superset of the head after an early stop)
+    const int lo = blockIdx.x * TK_TILE;
+    if (lo >= k_eff) return;                       // uniform
+    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
+        const int j = lo + t;
+        sk[t] = (j < k_eff) ? ~sel_key[j] : ~0ull;       // padding sorts last
+        si[t] = (j < k_eff) ? sel_idx[j] : 0xffffffffu;
+    }
+    __syncthreads();
+    for (int size = 2; size <= TK_TILE; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int t = threadIdx.x;
+            const int pos = 2 * t - (t & (stride - 1));
+            const int par = pos + stride;
+            const bool up = (pos & size) == 0;
+            const uint64_t ka = sk[pos], kb = sk[par];
+            const uint32_t ia = si[pos], ib = si[par];
+            if (comp_less<TIE>(kb, ib, ka, ia, obj) == up) {
+                sk[pos] = kb; sk[par] = ka;
+                si[pos] = ib; si[par] = ia;
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
+        tile_key[lo + t] = sk[t];
+        tile_idx[lo + t] = si[t];
+    }
+}
+
 // TIE: 0 plain composite compare, 1 obj_improve as tie key (mode COMBALL), 2 decided by the mode the
 // selection resolved on the device (TK_MODE_COMBAUTO): one uniform branch at entry picks the
 // specialised body, the comparators stay branch-free
@@ -544,6 +577,55 @@ __global__ __launch_bounds__(TK_THREADS) void tk_tilesort_kernel(const TopkWs *w
         tilesort_body<true>(ws, sel_key, sel_idx, tile_key, tile_idx, obj, sk, si);
     else
         tilesort_body<false>(ws, sel_key, sel_idx, tile_key, tile_idx, obj, sk, si);
+}
+
+template <bool TIE>
+__device__ __forceinline__ void mergerank_body(int64_t base, double score_add, const TopkWs *ws, const uint64_t *tile_key,
+                                               const uint32_t *tile_idx, int64_t *idx_out, double *score_out,
+                                               const double *obj, uint64_t *sk, uint32_t *si)
+{
+    const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
+    if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
+    const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
+    for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 8 * TK_THREADS) {      // 8 loads in flight per thread
+        uint64_t kk[8];
+        uint32_t ii[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * TK_THREADS + threadIdx.x;
+            const bool in = j < ntiles * TK_TILE;
+            kk[u] = in ? tile_key[j] : 0ull;
+            ii[u] = in ? tile_idx[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * TK_THREADS + threadIdx.x;
+            if (j < ntiles * TK_TILE) { sk[j] = kk[u]; si[j] = ii[u]; }
+        }
+    }
+    __syncthreads();
+    const int e = blockIdx.x * TK_THREADS + threadIdx.x;      // position in the tiled array
+    if (e >= ntiles * TK_TILE) return;
+    const uint64_t ke = sk[e];
+    const uint32_t ie = si[e];
+    if (ie == 0xffffffffu && ke == ~0ull) return;             // padding
+    const int te = e / TK_TILE;
+    int rank = e - te * TK_TILE;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t == te) continue;
+        // lower bound of e's composite inside tile t (all composites are distinct)
+        int lo = 0, hi = TK_TILE;
+        while (lo < hi) {                                     // <= 10 steps
+            const int mid = (lo + hi) >> 1;
+            const bool less = comp_less<TIE>(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie, obj);
+            lo = less ? mid + 1 : lo;
+            hi = less ? hi : mid;
+        }
+        rank += lo;
+    }
+    if (rank >= k_eff) return;                                // superset entries beyond the head
+    idx_out[rank] = base + (int64_t)ie;
+    score_out[rank] = score_of(~ke) + score_add;
 }
 
 template <int TIE>
@@ -746,7 +828,6 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
                                     int64_t *d_idx_out, double *d_score_out, bool compacted, int raw, int64_t base,
                                     int64_t emit_limit = TK_MAXK)
 {
-    h->sort_deferred = false;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     if (!compacted) {
@@ -756,18 +837,16 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             // cooperative launch: the runtime guarantees that all workgroups of the grid are resident
             // together, which is what the kernel's grid barriers need (256 workgroups of 256 threads on
             // 256 CUs); its waits stay bounded anyway
-            uint64_t *keys_arg = h->d_key_a;
+            const uint64_t *keys_arg = h->d_key_a;
             uint64_t *sk_arg = h->d_sel_key;
             uint32_t *si_arg = h->d_sel_idx;
-            int64_t n_arg = n, k_arg = k, chunk_arg = chunk, sel_arg = 0;
-            int mode_arg = 0;
-            const double *np_arg = nullptr;
-            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg, &mode_arg, &sel_arg, &np_arg, &np_arg};
+            int64_t n_arg = n, k_arg = k, chunk_arg = chunk;
+            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg};
             if (h->coop_launch)
-                HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
+                HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else
-                hipLaunchKernelGGL(tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                                   h->d_sel_key, h->d_sel_idx, 0, (int64_t)0, (const double *)nullptr, (const double *)nullptr);
+                hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+                                   h->d_sel_key, h->d_sel_idx);
         } else {
             hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
             hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
@@ -794,13 +873,6 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             hipLaunchKernelGGL(tk_mergerank_big_kernel<false>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,
                                d_idx_out, d_score_out, tie_obj, raw, emit_limit);
         }
-    } else if (h->defer_sort && h->fused_tail && !h->shard_rec && !raw) {
-        // the caller's epilogue launch sorts, ranks and generates the rows (round_finish_kernel)
-        h->sort_deferred = true;
-        h->ps_ws = ws;
-        h->ps_obj = tie_obj;
-        h->ps_tie = mode == TK_MODE_COMBAUTO ? 2 : (mode == TK_MODE_COMBALL ? 1 : 0);
-        h->ps_score_add = score_add;
     } else {
         if (raw) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: raw output needs the big-head merge");
 #define TK_SORT_LAUNCH(T)                                                                                                  \
@@ -841,21 +913,13 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
     const bool small = !keys_done && n <= maxk;
-    bool compacted = small;
     if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
-    } else if (!keys_done && h->fused_tail && !h->coop_launch) {
-        // pass 0 .. 7, count and compaction in ONE launch (tk_refine_kernel<true>)
-        int64_t chunk = (n + grid - 1) / grid;
-        chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
-        hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                           h->d_sel_key, h->d_sel_idx, mode, sel, eig, obj);
-        compacted = true;
     } else if (!keys_done) {
         hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
     }
-    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, compacted, 0, h->base);
+    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base);
     if (rc) return rc;
     if (d_counters_out) *d_counters_out = ws->counters;
     return 0;

@@ -91,7 +91,7 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
         const int64_t cls = ld_i64(&ws->counters[0]);
         need = k < cls ? k : cls;
         prefix = 0;
-        if (t == 0) st_i64(&ws->counters[3], need);      // k_eff for the later passes (possibly of this launch) and kernels
+        if (t == 0) st_i64(&ws->counters[3], need);      // k_eff for the later passes and kernels
     } else {
         need = ld_i64(&ws->state[p].need);       // written by the previous launch, or by another block of this one
         prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
@@ -208,157 +208,3 @@ __device__ __forceinline__ uint64_t masked_key(int mode, double eig, double obj)
     return (obj > 0.0 && viol) ? key_of(obj) : 0ull;
 }
 
-// ------------------------------------------------------------------------------------------
-// Pieces shared by the selection kernels (topk.hip) and the fused round epilogue (score.hip).
-#define TK_SPIN_LIMIT (1 << 16)      // x s_sleep: a few milliseconds; a legitimate wait is tens of microseconds
-#define TK_TILE 512
-
-// One-shot grid barrier `b` of a selection (its arrival counter starts at zero with the workspace).
-// Every thread's device-scope atomics are drained before the workgroup arrives.  Bounded like the
-// wait of tk_hist_rest_kernel: if the other workgroups do not show up (the GPU shared with a kernel
-// that keeps them from starting) counters[4] marks the selection void and everybody leaves.
-static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
-{
-    __shared__ int bar_ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&ws->bar[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        uint32_t it = 0;
-        while (ld_u32(&ws->bar[b]) < nblocks) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
-                st_i64(&ws->counters[4], 1);
-                ok = 0;
-                break;
-            }
-        }
-        bar_ok = ok;
-    }
-    __syncthreads();
-    return bar_ok != 0;
-}
-
-// COH = true: the arrays are handed between workgroups of ONE launch (fused epilogue): device-scope
-// atomic stores / loads, which go to the coherence point instead of the XCD-private L2.
-template <bool COH, typename T>
-__device__ __forceinline__ void st_x(T *p, T v)
-{
-    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool COH, typename T>
-__device__ __forceinline__ T ld_x(const T *p)
-{
-    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-
-// obj != NULL (mode COMBALL): equal keys are ordered by obj_improve descending before the index --
-// the first stable sort of the reference (:601) under its second one (:625).  The scores are only
-// fetched for equal keys (rare unless the point is degenerate); padding never reaches the fetch.
-// The sort kernels are instantiated twice: TIE = false is the plain composite compare (a memory
-// fetch and a branch inside the comparator cost the common modes 30 % of both kernels).
-template <bool TIE>
-__device__ __forceinline__ bool comp_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, const double *obj)
-{
-    if constexpr (!TIE) {
-        return ka < kb || (ka == kb && ia < ib);
-    } else {
-        if (ka != kb) return ka < kb;
-        if (ia != 0xffffffffu && ib != 0xffffffffu) {
-            const uint64_t oa = key_of(obj[ia]), ob = key_of(obj[ib]);
-            if (oa != ob) return oa > ob;
-        }
-        return ia < ib;
-    }
-}
-
-// Final order of the selected pairs, (key desc, idx asc) = ascending composite (~key, idx):
-//   1. bitonic sort of 512-entry tiles in LDS (one workgroup per tile);
-//   2. every entry's final rank = its position in its own tile + the number of entries preceding it
-//      in every other tile (binary searches over tiles staged in LDS; composites are unique).
-template <bool TIE, bool COH = false>
-__device__ __forceinline__ void tilesort_body(const TopkWs *ws, const uint64_t *sel_key, const uint32_t *sel_idx,
-                                              uint64_t *tile_key, uint32_t *tile_idx, const double *obj, uint64_t *sk,
-                                              uint32_t *si)
-{
-    const int k_eff = (int)ws->n_sel;              // compacted entries (a superset of the head after an early stop)
-    const int lo = blockIdx.x * TK_TILE;
-    if (lo >= k_eff) return;                       // uniform
-    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
-        const int j = lo + t;
-        sk[t] = (j < k_eff) ? ~sel_key[j] : ~0ull;       // padding sorts last
-        si[t] = (j < k_eff) ? sel_idx[j] : 0xffffffffu;
-    }
-    __syncthreads();
-    for (int size = 2; size <= TK_TILE; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int t = threadIdx.x;
-            const int pos = 2 * t - (t & (stride - 1));
-            const int par = pos + stride;
-            const bool up = (pos & size) == 0;
-            const uint64_t ka = sk[pos], kb = sk[par];
-            const uint32_t ia = si[pos], ib = si[par];
-            if (comp_less<TIE>(kb, ib, ka, ia, obj) == up) {
-                sk[pos] = kb; sk[par] = ka;
-                si[pos] = ib; si[par] = ia;
-            }
-            __syncthreads();
-        }
-    }
-    for (int t = threadIdx.x; t < TK_TILE; t += TK_THREADS) {
-        st_x<COH>(&tile_key[lo + t], sk[t]);
-        st_x<COH>(&tile_idx[lo + t], si[t]);
-    }
-}
-
-template <bool TIE, bool COH = false>
-__device__ __forceinline__ void mergerank_body(int64_t base, double score_add, const TopkWs *ws, const uint64_t *tile_key,
-                                               const uint32_t *tile_idx, int64_t *idx_out, double *score_out,
-                                               const double *obj, uint64_t *sk, uint32_t *si)
-{
-    const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
-    if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
-    const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
-    for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 8 * TK_THREADS) {      // 8 loads in flight per thread
-        uint64_t kk[8];
-        uint32_t ii[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * TK_THREADS + threadIdx.x;
-            const bool in = j < ntiles * TK_TILE;
-            kk[u] = in ? ld_x<COH>(&tile_key[j]) : 0ull;
-            ii[u] = in ? ld_x<COH>(&tile_idx[j]) : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * TK_THREADS + threadIdx.x;
-            if (j < ntiles * TK_TILE) { sk[j] = kk[u]; si[j] = ii[u]; }
-        }
-    }
-    __syncthreads();
-    const int e = blockIdx.x * TK_THREADS + threadIdx.x;      // position in the tiled array
-    if (e >= ntiles * TK_TILE) return;
-    const uint64_t ke = sk[e];
-    const uint32_t ie = si[e];
-    if (ie == 0xffffffffu && ke == ~0ull) return;             // padding
-    const int te = e / TK_TILE;
-    int rank = e - te * TK_TILE;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t == te) continue;
-        // lower bound of e's composite inside tile t (all composites are distinct)
-        int lo = 0, hi = TK_TILE;
-        while (lo < hi) {                                     // <= 10 steps
-            const int mid = (lo + hi) >> 1;
-            const bool less = comp_less<TIE>(sk[t * TK_TILE + mid], si[t * TK_TILE + mid], ke, ie, obj);
-            lo = less ? mid + 1 : lo;
-            hi = less ? hi : mid;
-        }
-        rank += lo;
-    }
-    if (rank >= k_eff) return;                                // superset entries beyond the head
-    st_x<COH>(&idx_out[rank], base + (int64_t)ie);
-    st_x<COH>(&score_out[rank], score_of(~ke) + score_add);
-}
