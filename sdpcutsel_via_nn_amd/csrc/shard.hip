@@ -117,9 +117,13 @@ extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, in
                        count, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, (int64_t *)h->pinned_dev);
     // rows of the merged head that live on this shard (the others are marked ks = 0, lam = NaN),
     // stored -- with the merged ids and scores -- straight into the host block
-    rc = launch_round_rows(h, sel_size, nullptr, d_mi, d_ms, coef_ld, h->pinned_dev, (int64_t)hdr_b);
+    // (completion: the rows kernel's last workgroup stores the round's serial number into word 7 of the
+    // first header -- a pad word of the record -- and the host polls it, see wait_round_done)
+    const int64_t serial = ++h->round_serial;
+    rc = launch_round_rows(h, sel_size, nullptr, d_mi, d_ms, coef_ld, h->pinned_dev, (int64_t)hdr_b, serial);
     if (rc) return rc;
-    HIP_TRY(h, sdpcut_sync(h));
+    rc = wait_round_done(h, (const int64_t *)h->pinned + 7, serial);
+    if (rc) return rc;
     *block = h->pinned;
     return SDPCUT_OK;
 }
