@@ -124,6 +124,7 @@ extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, in
     if (rc) return rc;
     rc = wait_round_done(h, (const int64_t *)h->pinned + 7, serial);
     if (rc) return rc;
+    ((int64_t *)h->pinned)[7] = 0;      // the caller sees the record's pad word, not the completion mark
     *block = h->pinned;
     return SDPCUT_OK;
 }
