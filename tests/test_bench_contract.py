@@ -91,3 +91,28 @@ def test_bench_under_torchrun_with_real_rccl_prints_one_json_line():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and 5e8 < d["value"] < 1e10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,extra", [("c2", []), ("c4", ["--steps", "2"])])
+def test_bench_two_ranks_sharing_the_gpu(config, extra):
+    """The N = 2 form of the driver's launch (torch.distributed.run, two ranks) rehearsed on the one-GPU
+    box: both ranks on cuda:0 (SDPCUT_BENCH_ONE_DEVICE=1), the all-gather staged through gloo
+    (SDPCUT_BENCH_BACKEND=gloo).  One JSON line from rank 0, n_gpus = 2, the whole-job value = the
+    candidates of BOTH ranks over the slowest rank's time; c4 splits its 1e8 candidates between the ranks
+    (strong scaling, ids from the on-device generator)."""
+    env = dict(os.environ, SDPCUT_BENCH_ONE_DEVICE="1", SDPCUT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+           "--no-cpu-baseline", "--no-secondary", "--config", config] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    per_rank = 10 ** 6 if config == "c2" else 10 ** 8 // 2
+    assert d["n_gpus"] == 2 and d["config"]["candidates_per_gpu"] == per_rank
+    assert d["scaling"] == ("weak" if config == "c2" else "strong")
+    assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["value"] > 3e8          # two ranks time-share one GPU: roughly the one-GPU rate in total

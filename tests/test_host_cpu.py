@@ -235,16 +235,17 @@ main()
 '''
 
 
-def test_sharded_selection_gloo_world2(oracle, tmp_path):
-    """world_size-2 rehearsal (gloo): per-shard heads + all-gather + merge reproduce the
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_selection_gloo(oracle, tmp_path, world):
+    """world_size-2 and -8 rehearsal (gloo): per-shard heads + all-gather + merge reproduce the
     single-list ranking head bit-exactly for strategies 1, 2 and 4 (both regimes of the
-    combined scan, heavy ties included)."""
+    combined scan, heavy ties included).  Eight ranks = the shape of the driver's largest run."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % dict(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29641 + world), OMP_NUM_THREADS="1")
     procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
