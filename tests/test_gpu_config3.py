@@ -120,6 +120,20 @@ def test_live_rounds_dim4_device_cover():
     assert all(s < 0.25 for s in st[1:]), st
     e = cs._agg_list[1700214]                                                  # records on demand, from the device
     assert len(e[0]) in (2, 3, 4) and len(e[1]) == len(e[0]) * (len(e[0]) + 1) // 2
+    # rank-list entries over a list that only exists on the device: built from fetched index sets
+    vv = np.asarray(cs._my_prob.get_values())
+    rl = cs._sel_eigcut_by_ordering_on_measure(2, vv, 99)
+    head = rl[0:20]
+    L = cs._nb_lifted
+    for idx, score, curr_pt, X_slice in head:
+        rec = cs._agg_list[idx]
+        assert isinstance(idx, int) and isinstance(score, float)
+        assert curr_pt == tuple(vv[L + i] for i in rec[0]) and X_slice == tuple(vv[i] for i in rec[1])
+    assert [x[1] for x in head] == sorted((x[1] for x in head), reverse=True)
+    feas = cs._sel_eigcut_by_ordering_on_measure(1, vv, 99)
+    if len(feas):
+        f = feas[0:10][0]
+        assert f[3] == len(f[0]) and f[2] == cs._agg_list[f.agg_idx][1]
 
 
 @pytest.mark.parametrize("point", ["mccormick_vertex", "generic"])
