@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the k = 2, 4, 5 single-GPU rates")
     ap.add_argument("--device-point", action="store_true",
                     help="A/B: take the LP point from a device buffer (the round-1 bracket) instead of host memory")
-    ap.add_argument("--fuse", action="store_true", help="A/B: run the selection's key pass inside the score kernel")
+    ap.add_argument("--no-fuse-keys", action="store_true",
+                    help="A/B: the selection runs its own key pass instead of starting from the score kernel's histograms")
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
@@ -208,8 +209,8 @@ def main():
     def make_scorer(k, count, seed, base):
         """handle with the network of size k, the instance of (nb_vars, seed 7) and `count` candidates"""
         sc = _capi.Scorer(local_rank)
-        if args.fuse:
-            sc.set_option(_capi.OPT_FUSE_KEYS, 1)
+        if args.no_fuse_keys:
+            sc.set_option(_capi.OPT_FUSE_KEYS, 0)
         if args.no_auto_regime:
             sc.set_option(_capi.OPT_AUTO_REGIME, 0)
         if args.no_fused_tail:
@@ -257,9 +258,8 @@ def main():
                 # by the device into the handle's pinned host block (copy=False hands out views of it)
                 res = sc.select_round(4, SEL, copy=False)
             else:
-                # score the shard -> packed head record -> ONE all-gather (RCCL) -> replicated merge ->
+                # score the shard + packed head record (one call) -> ONE all-gather (RCCL) -> replicated merge ->
                 # each rank generates the rows of its own candidates -> one D2H, one host sync
-                sc.score(_capi.EIG | _capi.NN)
                 res = sel.select_round(4, SEL)
             if timed:
                 kernel_ms.append(sc.last_timing()[0])

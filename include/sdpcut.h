@@ -54,11 +54,11 @@ enum { SDPCUT_PART_STRONG = 104 };
 
 /* kernel variants for sdpcut_set_option(SDPCUT_OPT_KERNEL, ...) */
 enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 };
-/* SDPCUT_OPT_FUSE_KEYS = 1: sdpcut_select_round lets the score kernels run the first pass of the
- * top-k selection (keys, leading-digit histogram, class counters) instead of a separate pass
- * over the scores.  Default 0: on MI355X the two variants take the same time per round (the
- * separate pass costs 16 us, the fused epilogue 15 us), and the unfused score kernel is the
- * cleaner unit to measure. */
+/* SDPCUT_OPT_FUSE_KEYS (default 1): sdpcut_select_round lets the score kernels count their scores by
+ * the leading radix digit of the selection keys (per workgroup in LDS, flushed with no-return atomics)
+ * together with the violated / positive counters; the top-k selection then starts at its second digit
+ * and builds the keys from the scores while it reads them, so the separate key pass over the scores
+ * (17.5 us per round at 10^6 candidates) disappears.  0: the selection runs its own first pass. */
 /* SDPCUT_OPT_AUTO_REGIME (default 1): sdpcut_select_round with the combined strategy lets the score
  * kernels count the strong candidates and the selection pick its regime on the device (one selection,
  * no host round trip whether or not sel_size strong candidates exist).  0: the selection assumes the
@@ -78,8 +78,9 @@ enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, S
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier
  * timed out because other work kept its workgroups from starting, or a tie group overflowed the sort
- * buffers) and were answered by the full-sort path instead -- same result, ~1 ms instead of ~0.1 ms. */
-enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2 };
+ * buffers) and were answered by the full-sort path instead -- same result, ~1 ms instead of ~0.1 ms.
+ * SDPCUT_STAT_SCORED = the measures (SDPCUT_EIG | SDPCUT_NN) scored at the current point. */
+enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3 };
 int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value);
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */
@@ -264,7 +265,10 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
  * int64 words
  *     [list length, nb_violated, nb_positive, entries written, void flag, 0, 0, 0 |
  *      count scores (fp64 bits) | count GLOBAL ids]
- * padded with (-inf, INT64_MAX); 1 <= count <= 8192.
+ * padded with (-inf, INT64_MAX); 1 <= count <= 8192.  Measures the strategy needs and sdpcut_score has
+ * not computed since the last sdpcut_set_point are scored by this call (a sharded round is set_point,
+ * shard_head, all-gather, shard_finish); when none of them has been, the score kernels also prepare the
+ * selection's first radix digit (SDPCUT_OPT_FUSE_KEYS).
  *
  * sdpcut_shard_finish_round: d_allrec holds the `world` records in rank order.  Merges them
  * by (score descending, id ascending) -- the order of the reference's stable sort on one list

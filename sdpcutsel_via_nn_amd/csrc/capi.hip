@@ -150,6 +150,49 @@ static void free_candidates(sdpcut_ctx *h)
     h->N = 0; h->scored = 0; h->last_total = -1;
 }
 
+// Scores of a round's selection (strategy strat, head of `cap` entries), not computed yet at this point:
+// *stage / *auto_out are what topk_select_enqueue / rank_fast_enqueue take.
+// If nothing has been scored at the point and the head comes from the radix select, the score kernels work
+// for the selection that follows.  Combined strategy (allow_auto): they count the strong candidates into
+// its workspace and the selection resolves its regime on the device (at least sel_size strong ones:
+// those, + BIG_M; fewer: every entry visited) -- one selection and no host round trip in either regime.
+// SDPCUT_OPT_FUSE_KEYS: they also count the class members by the leading digit of the selection keys, so
+// that the selection starts at its second digit and needs no key pass (the every-entry-visited regime of
+// the combined strategy runs its own first digit inside the selection).
+int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap, uint32_t need, bool allow_auto, int *stage,
+                        bool *auto_out)
+{
+    *stage = 0;
+    *auto_out = false;
+    int rc;
+    const int fast_mode = (h->scored & need) == 0 ? rank_fast_mode(h, strat, sel_size, cap, nullptr) : 0;
+    const bool want_auto = allow_auto && strat == SDPCUT_STRAT_COMB;
+    const bool count_digit = h->fuse_keys && topk_fuse_ok(h, cap);
+    if (fast_mode && (want_auto || count_digit)) {
+        void *ws = nullptr;
+        rc = topk_begin(h, &ws, nullptr);
+        if (rc) return rc;
+        int64_t *strong = (need == (SDPCUT_EIG | SDPCUT_NN)) ? topk_strong_counter(ws) : nullptr;
+        bool counted = false;
+        if (count_digit) {
+            ScoreFuse fuse;
+            fuse.ws = ws;
+            fuse.mode = fast_mode;
+            rc = launch_score(h, need, &fuse, &counted, strong);
+        } else {
+            rc = launch_score(h, need, nullptr, nullptr, strong);
+        }
+        if (rc) return rc;
+        h->scored |= need;
+        *stage = counted ? 3 : 1;
+        *auto_out = want_auto;
+    } else if ((h->scored & need) != need) {
+        rc = sdpcut_score(h, need & ~h->scored);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int sdpcut_destroy(sdpcut_handle h)
@@ -206,6 +249,7 @@ int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value)
     switch (which) {
     case SDPCUT_STAT_ROUNDS: *value = h->stat_rounds; return SDPCUT_OK;
     case SDPCUT_STAT_SELECT_FALLBACKS: *value = h->stat_fallbacks; return SDPCUT_OK;
+    case SDPCUT_STAT_SCORED: *value = h->have_point ? (int64_t)h->scored : 0; return SDPCUT_OK;
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown statistic");
 }
@@ -668,37 +712,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     int64_t cap = sel_size < h->N ? sel_size : h->N;
     int stage = 0;               // how far the selection's first pass has got (topk_select_enqueue)
     bool auto_regime = false;
-    if (h->fuse_keys && (h->scored & need) == 0 && rank_fast_mode(h, strat, sel_size, cap, nullptr)) {
-        // nothing scored at this point yet and the head comes from the radix select: let the score
-        // kernels run the selection's first pass (keys, leading digit, class counters) as well
-        ScoreFuse fuse;
-        fuse.mode = rank_fast_mode(h, strat, sel_size, cap, nullptr);
-        fuse.k = cap;
-        rc = topk_begin(h, &fuse.ws, &fuse.keys);
-        if (rc) return rc;
-        bool keys_done = false;
-        rc = launch_score(h, need, &fuse, &keys_done);
-        if (rc) return rc;
-        h->scored |= need;
-        stage = keys_done ? 2 : 1;
-    } else if (h->auto_regime && strat == SDPCUT_STRAT_COMB && (h->scored & need) == 0 &&
-               rank_fast_mode(h, strat, sel_size, cap, nullptr)) {
-        // combined strategy, both measures scored in this call: the score kernels count the strong
-        // candidates into the selection's workspace, and the selection resolves its regime on the
-        // device (at least sel_size strong ones: those, + BIG_M; fewer: every entry visited) -- one
-        // selection and no host round trip in either regime
-        void *ws = nullptr;
-        rc = topk_begin(h, &ws, nullptr);
-        if (rc) return rc;
-        rc = launch_score(h, need, nullptr, nullptr, topk_strong_counter(ws));
-        if (rc) return rc;
-        h->scored |= need;
-        stage = 1;
-        auto_regime = true;
-    } else if ((h->scored & need) != need) {
-        rc = sdpcut_score(h, need & ~h->scored);
-        if (rc) return rc;
-    }
+    rc = score_for_selection(h, strat, sel_size, cap, need, h->auto_regime, &stage, &auto_regime);
+    if (rc) return rc;
     *n_out = 0;
     *cap_out = cap;
     *block = nullptr;

@@ -57,7 +57,7 @@ struct sdpcut_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
     int kernel_variant = SDPCUT_KERNEL_MFMA;
-    bool fuse_keys = false;        // SDPCUT_OPT_FUSE_KEYS (measured: no gain, see include/sdpcut.h)
+    bool fuse_keys = true;         // SDPCUT_OPT_FUSE_KEYS (see include/sdpcut.h)
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)
@@ -147,13 +147,11 @@ int ensure_pinned(sdpcut_ctx *h, size_t bytes);  // capi.hip: grow h->pinned / h
     } while (0)
 
 // score.hip
-// Optional fusion of the top-k selection's first pass into the score kernels (ScoreArgs::tk):
-// ws = zeroed TopkWs of the selection that follows, keys = its key array [N].
+// Optional: the score kernels count their scores by the leading radix digit of the selection keys
+// (ScoreArgs::tk): ws = zeroed TopkWs of the selection that follows (topk_begin).
 struct ScoreFuse {
     void *ws;
-    uint64_t *keys;
-    int mode;      // TK_MODE_* of topk_dev.h
-    int64_t k;     // head length asked from the selection
+    int mode;      // TK_MODE_FEAS / OPT / STRONG of topk_dev.h: whose keys to count
 };
 // strong_out (optional, device, 8 int64 replicas): the launches add the number of candidates with
 // obj_improve > 0 and lambda_min < -1e-15 to strong_out[workgroup % 8] (needs both flags; used by the device-resolved combined selection)
@@ -167,6 +165,8 @@ int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int
                       int coef_ld, void *block, int64_t hdr_bytes = 64, int64_t done_serial = 0);
 int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n);
 int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial);   // capi.hip
+int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap, uint32_t need, bool allow_auto, int *stage,
+                        bool *auto_out);                                   // capi.hip
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,
                      double *d_vals, double *d_vecs);
 int launch_nn_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_in, double *d_out);
@@ -202,8 +202,9 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
                         double *d_score_out, const int64_t **d_counters_out, int stage = 0, int64_t sel = 0);
 // allocate / zero (or swap in the pre-zeroed) workspace of the next selection and return it together
 // with the key array: what a score launch needs to run the selection's first pass itself
-// (ScoreFuse); follow with topk_select_enqueue(..., keys_done = true)
+// (ScoreFuse); follow with topk_select_enqueue(..., stage = 3)
 int topk_begin(sdpcut_ctx *h, void **ws, uint64_t **keys);
+bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k);     // may a score launch take a ScoreFuse for a head of k entries?
 int64_t *topk_strong_counter(void *ws);      // TopkWs::strong_rep (TK_SREP = 8 replicas) of a workspace handed out by topk_begin
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[5]);

@@ -36,14 +36,15 @@ struct ScoreArgs {
     double *eig_out;      // [N] caller order
     double *obj_out;      // [N]
     uint32_t flags;
-    // Fused first pass of the top-k selection (topk_dev.h; tk == nullptr: off): the kernel that
-    // produces the scores also writes their radix keys, the histogram of the leading digit and the
-    // class counters, which saves the separate key pass over 24 MB (tk_keys_kernel, ~16 us).
+    // Leading-digit histogram of the top-k selection that follows (topk_dev.h; tk == nullptr: off): the
+    // kernel that produces the scores also counts the members of the selection's class by the first radix
+    // digit of their keys -- in LDS per workgroup, flushed with no-return atomics at its end (no ticket,
+    // nobody waits) -- together with the violated / positive counters.  The selection then starts at its
+    // second digit and builds the keys from the scores as it reads them: the separate key pass
+    // (tk_keys_kernel, 17.5 us per round) is gone.  Candidates outside the class (key 0) are not counted:
+    // the selection never looks below the class.
     TopkWs *tk;
-    uint64_t *tk_keys;     // [N] caller order
-    int tk_mode;
-    int64_t tk_k;
-    uint32_t tk_blocks;    // blocks of ALL score launches of this call (ticket target of the pass)
+    int tk_mode;           // TK_MODE_FEAS / OPT / STRONG: the kernel's FUSE template argument
     // optional: += number of candidates with obj_improve > 0 and lambda_min < -1e-15 (the "strong" class
     // of the combined strategy, cut_select_qp.py:607-613); lets the selection that follows pick its
     // regime on the device.  Needs both flags.
@@ -427,11 +428,11 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #endif
 
 // ------------------------------------------------------------------------------------------
-// MFMA kernel.  K candidate size, H hidden width, NH hidden layers; FUSE: also run the first pass
-// of the top-k selection (ScoreArgs::tk).
+// MFMA kernel.  K candidate size, H hidden width, NH hidden layers; FUSE = TK_MODE_FEAS / OPT / STRONG:
+// also count the class members by the leading radix digit of that mode's selection keys (ScoreArgs::tk).
 // CLAMP = false (NetDev::unclamped_ok): the tansig clamps are dropped and the staged inputs are
 // clamped to [-3, 3] instead (inactive for every x in [0, 1], |q| <= 1/k, see sdpcut_set_network).
-template <int K, int H, int NH, bool FUSE = false, bool CLAMP = true>
+template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true>
 __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 {
     constexpr int M = K * (K + 1) / 2;
@@ -484,14 +485,13 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     }
 #endif
 
-    // fused first pass of the top-k selection (A.tk != nullptr)
+    // leading-digit histograms of the selection that follows (A.tk != nullptr)
     __shared__ uint32_t tk_hist[256];
-    __shared__ uint32_t tk_cnt[3];
-    uint32_t c_class = 0, c_viol = 0, c_pos = 0;
-    uint32_t c_strong = 0;        // per wave (lane 0 keeps it)
-    if constexpr (FUSE) {
+    __shared__ uint32_t tk_cnt[2];
+    uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
+    if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
-        if (threadIdx.x < 3) tk_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
         __syncthreads();
     }
 
@@ -525,15 +525,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         }
         PHASE_MARK(2);
         if (!(A.flags & SDPCUT_NN)) {           // uniform branch
-            if constexpr (FUSE) {
-                uint64_t key = 0;
-                if (valid) {
-                    key = masked_key(A.tk_mode, lam, 0.0);
-                    A.tk_keys[out_idx] = key;
-                    c_class += (A.tk_mode == TK_MODE_OPT) ? 1u : (key != 0ull);
-                    c_viol += lam < SDPCUT_NEG_EIGVAL;
-                }
-                hist_add(tk_hist, (uint32_t)(key >> 56), valid);
+            if constexpr (FUSE != 0) {
+                const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
+                hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
+                c_viol += viol;
             }
             continue;
         }
@@ -682,19 +677,13 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
             double obj = cd.negSM;
             obj = obj + y * cd.max_elem;
             if (valid) A.obj_out[out_idx] = obj;
-            if (A.strong_out)       // uniform
-                c_strong += (uint32_t)__popcll(__ballot(valid && obj > 0.0 && lam < SDPCUT_NEG_EIGVAL));
-            if constexpr (FUSE) {
-                const bool have_eig = (A.flags & SDPCUT_EIG) != 0;
-                uint64_t key = 0;
-                if (valid) {
-                    key = masked_key(A.tk_mode, lam, obj);
-                    A.tk_keys[out_idx] = key;
-                    c_class += (A.tk_mode == TK_MODE_OPT) ? 1u : (key != 0ull);
-                    c_viol += have_eig && (lam < SDPCUT_NEG_EIGVAL);
-                    c_pos += obj > 0.0;
-                }
-                hist_add(tk_hist, (uint32_t)(key >> 56), valid);
+            const bool viol = valid && (A.flags & SDPCUT_EIG) && lam < SDPCUT_NEG_EIGVAL, pos = valid && obj > 0.0;
+            c_strong += viol && pos;
+            if constexpr (FUSE != 0) {
+                c_viol += viol;
+                c_pos += pos;
+                const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
+                hist_add_few(tk_hist, (uint32_t)(key_of(FUSE == TK_MODE_FEAS ? -lam : obj) >> 56), member);
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
@@ -705,21 +694,33 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         __shared__ uint32_t s_strong;
         if (threadIdx.x == 0) s_strong = 0;
         __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) c_strong += __shfl_xor((int)c_strong, off);
         if (lane == 0 && c_strong) atomicAdd(&s_strong, c_strong);
         __syncthreads();
         if (threadIdx.x == 0 && s_strong)
             __hip_atomic_fetch_add((unsigned long long *)&A.strong_out[blockIdx.x & 7], (unsigned long long)s_strong,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (FUSE) {   // same tail as tk_keys_kernel: class counters, then the pass hand-off
-        if (c_class) atomicAdd(&tk_cnt[0], c_class);
-        if (c_viol) atomicAdd(&tk_cnt[1], c_viol);
-        if (c_pos) atomicAdd(&tk_cnt[2], c_pos);
+    if constexpr (FUSE != 0) {
+        // No ticket, nobody waits: the kernel boundary orders the atomics before the selection.  (A ticket per
+        // workgroup -- the last one resolving the digit, as the selection's own passes do -- costs a drain
+        // of the workgroup's stores plus an atomic round trip before each of the 2048 workgroups may
+        // retire: +14 us on this kernel.)
+        for (int off = 32; off > 0; off >>= 1) {
+            c_viol += __shfl_xor((int)c_viol, off);
+            c_pos += __shfl_xor((int)c_pos, off);
+        }
+        if (lane == 0) {
+            if (c_viol) atomicAdd(&tk_cnt[0], c_viol);
+            if (c_pos) atomicAdd(&tk_cnt[1], c_pos);
+        }
         __syncthreads();
-        if (threadIdx.x < 3 && tk_cnt[threadIdx.x])
-            atomicAdd((unsigned long long *)&A.tk->counters[threadIdx.x], (unsigned long long)tk_cnt[threadIdx.x]);
-        if (blockIdx.x == 0 && threadIdx.x == 0) st_i64(&A.tk->mode, A.tk_mode);
-        finish_pass(A.tk, 0, A.tk_k, tk_hist, A.tk_blocks);
+        if (threadIdx.x < 2 && tk_cnt[threadIdx.x])
+            __hip_atomic_fetch_add((unsigned long long *)&A.tk->counters[1 + threadIdx.x], (unsigned long long)tk_cnt[threadIdx.x],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk_hist[threadIdx.x])
+            __hip_atomic_fetch_add(&A.tk->hist[0][blockIdx.x % TK_HREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1204,9 +1205,6 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double *Am, const 
 #ifndef SDPCUT_MFMA_BLOCKS_PER_CU
 #define SDPCUT_MFMA_BLOCKS_PER_CU 8
 #endif
-#ifndef SDPCUT_FUSE_BLOCKS_PER_CU
-#define SDPCUT_FUSE_BLOCKS_PER_CU 2
-#endif
 
 static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
 {
@@ -1238,7 +1236,7 @@ static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
 
 template <int K>
 static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
-                          const ScoreFuse *fuse, uint32_t fuse_blocks, int64_t *strong_out)
+                          const ScoreFuse *fuse, int64_t *strong_out)
 {
     const Bucket &b = h->bucket[K];
     if (b.n == 0) return 0;
@@ -1247,10 +1245,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
-    A.tk_keys = fuse ? fuse->keys : nullptr;
     A.tk_mode = fuse ? fuse->mode : 0;
-    A.tk_k = fuse ? fuse->k : 0;
-    A.tk_blocks = fuse_blocks;
     A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
     A.net = h->net[K].dev;
     if ((flags & SDPCUT_NN) && !h->net[K].set)
@@ -1265,31 +1260,32 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         if (K == 5) SCORE_LAUNCH((score_valu_kernel<5, 64, 4>), grid, 256);
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
-        // With the fused key pass every workgroup ends with a histogram flush and a ticket: launch only
-        // the workgroups that are resident together (2 per CU), each looping over its tiles, so that the
-        // flush is paid once per resident workgroup, in the kernel's ragged tail.
-        const int grid = grid_for(h, ntiles, A.tk ? SDPCUT_FUSE_BLOCKS_PER_CU : SDPCUT_MFMA_BLOCKS_PER_CU);
-        if (A.tk && A.net.unclamped_ok) {      // (same arithmetic as the unfused kernel of the same network: bit-equal scores)
-            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true, false>), grid, 256);
-            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true, false>), grid, 256);
-            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true, false>), grid, 256);
-            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, true, false>), grid, 256);
-        } else if (A.tk) {
-            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, true>), grid, 256);
-            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, true>), grid, 256);
-            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, true>), grid, 256);
-            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, true>), grid, 256);
-        } else if (A.net.unclamped_ok) {
-            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, false, false>), grid, 256);
-            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, false, false>), grid, 256);
-            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, false, false>), grid, 256);
-            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, false, false>), grid, 256);
+        const int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
+        // (same arithmetic in every variant of one network: bit-equal scores)
+#define SCORE_MFMA_LAUNCH(F, C)                                                             \
+    do {                                                                                    \
+        if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, F, C>), grid, 256);          \
+        if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, F, C>), grid, 256);          \
+        if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, F, C>), grid, 256);          \
+        if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, F, C>), grid, 256);          \
+    } while (0)
+        const int f = A.tk ? A.tk_mode : 0;
+        if (f != 0 && f != TK_MODE_FEAS && f != TK_MODE_OPT && f != TK_MODE_STRONG)
+            return sdpcut_fail(h, SDPCUT_EINVAL, "score: no histogram variant for this selection mode");
+        if (f == TK_MODE_FEAS ? !(flags & SDPCUT_EIG) : (f != 0 && !(flags & SDPCUT_NN)))
+            return sdpcut_fail(h, SDPCUT_EINVAL, "score: the selection mode ranks by a measure this launch does not compute");
+        if (A.net.unclamped_ok) {
+            if (f == TK_MODE_STRONG) SCORE_MFMA_LAUNCH(TK_MODE_STRONG, false);
+            else if (f == TK_MODE_OPT) SCORE_MFMA_LAUNCH(TK_MODE_OPT, false);
+            else if (f == TK_MODE_FEAS) SCORE_MFMA_LAUNCH(TK_MODE_FEAS, false);
+            else SCORE_MFMA_LAUNCH(0, false);
         } else {
-            if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3>), grid, 256);
-            if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3>), grid, 256);
-            if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3>), grid, 256);
-            if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4>), grid, 256);
+            if (f == TK_MODE_STRONG) SCORE_MFMA_LAUNCH(TK_MODE_STRONG, true);
+            else if (f == TK_MODE_OPT) SCORE_MFMA_LAUNCH(TK_MODE_OPT, true);
+            else if (f == TK_MODE_FEAS) SCORE_MFMA_LAUNCH(TK_MODE_FEAS, true);
+            else SCORE_MFMA_LAUNCH(0, true);
         }
+#undef SCORE_MFMA_LAUNCH
     } else {
         const int64_t ntiles = (b.n + 63) / 64;
         const int grid = grid_for(h, ntiles, 16);
@@ -1301,18 +1297,16 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
 
 int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused, int64_t *strong_out)
 {
-    // the fused key pass lives in the MFMA kernel only: every non-empty size class must run on it;
-    // the last block over ALL launches resolves the digit, so it needs the total block count
-    uint32_t fuse_blocks = 0;
+    // the histograms are built by the MFMA kernel only: every non-empty size class must run on it
     if (fused) *fused = false;
     if (fuse) {
-        bool ok = h->kernel_variant == SDPCUT_KERNEL_MFMA;
+        bool ok = h->kernel_variant == SDPCUT_KERNEL_MFMA, any = false;
         for (int k = 2; k <= SDPCUT_MAX_K && ok; ++k) {
             if (h->bucket[k].n == 0) continue;
             ok = net_shape_ok(h, k, flags);
-            fuse_blocks += (uint32_t)grid_for(h, (h->bucket[k].n + 255) / 256, SDPCUT_FUSE_BLOCKS_PER_CU);
+            any = true;
         }
-        if (!ok || fuse_blocks == 0) fuse = nullptr;
+        if (!ok || !any) fuse = nullptr;
         else if (fused) *fused = true;
     }
     // the first non-empty size class carries the start event, the last one the stop event
@@ -1323,10 +1317,10 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
     hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
     if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
     int rc;
-    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, fuse_blocks, strong_out))) return rc;
-    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, fuse_blocks, strong_out))) return rc;
-    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, fuse_blocks, strong_out))) return rc;
-    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, fuse_blocks, strong_out))) return rc;
+    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, strong_out))) return rc;
+    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, strong_out))) return rc;
+    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, strong_out))) return rc;
+    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, strong_out))) return rc;
     return 0;
 }
 

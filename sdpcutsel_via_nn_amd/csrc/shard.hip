@@ -71,8 +71,16 @@ extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t coun
         return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: strategy must be 1, 2 or SDPCUT_PART_STRONG");
     const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
                           : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
-    if ((h->scored & need) != need) return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
+    if (h->N > 0 && (!h->have_point || !h->d_eig)) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
     HIP_TRY(h, hipSetDevice(h->device));
+    // Not scored at this point yet: the call scores the shard itself, and the score kernels count the leading
+    // digit of the selection keys on the way (score_for_selection) -- a sharded round needs no sdpcut_score.
+    int stage = 0;
+    bool auto_regime = false;
+    if (h->N > 0) {
+        int rc0 = score_for_selection(h, strat, 0, count, need, false, &stage, &auto_regime);
+        if (rc0) return rc0;
+    }
     int64_t *rec = (int64_t *)d_record;
     const int grid = (int)((count + 255) / 256);
     if (h->N > 0) {
@@ -82,7 +90,7 @@ extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t coun
         h->shard_rec = rec;
         h->shard_rec_count = count;
         h->shard_rec_len = strat == SDPCUT_STRAT_OPT ? h->N : -1;
-        int rc = rank_fast_enqueue(h, strat, 0, count, rec + SHARD_HDR + count, (double *)(rec + SHARD_HDR), &d_c4);
+        int rc = rank_fast_enqueue(h, strat, 0, count, rec + SHARD_HDR + count, (double *)(rec + SHARD_HDR), &d_c4, stage, false);
         h->shard_rec = nullptr;
         if (rc < 0) return rc;
         if (rc != 1) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: request not eligible for the select path");

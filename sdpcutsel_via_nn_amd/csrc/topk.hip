@@ -203,9 +203,17 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 // them): each workgroup counts its keys >= T, reserves its slice of the output with ONE fetch-add and
 // writes.  Masses of equal keys run the remaining digits behind grid barriers and cut the last group by
 // index, which needs the per-workgroup counts of all workgroups: one more barrier.
+//
+// ONFLY: the score kernels have already counted the leading digit (ScoreArgs::tk -> TopkWs::hist[0]) and
+// there is no key array: every workgroup resolves pass 0 for itself (same inputs, same result), and the
+// keys are built from the scores as they are read -- once, into the LDS cache, when the chunk fits.
+// Mode COMBAUTO resolved to COMBALL (fewer strong candidates than asked for -- the score kernels
+// counted the STRONG keys): this launch runs its own pass 0 first, histogram in TopkWs::hist_alt.
 #define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
+template <bool ONFLY>
 __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
-                                                               TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx)
+                                                               TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx, int mode,
+                                                               int64_t sel, const double *eig, const double *obj)
 {
     __shared__ uint32_t hist[256];
     __shared__ int go;
@@ -214,14 +222,40 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     __shared__ uint32_t c_gt, c_eq, gt_local, c_above;
     __shared__ unsigned long long slice;
     __shared__ uint64_t cache[TK_CACHE];
+    __shared__ TkState st1;                         // ONFLY: state after pass 0, resolved by this workgroup
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
     const bool use_cache = chunk <= TK_CACHE;      // uniform: the chunk is read from memory once
     bool cached = false;
-    int last_pass = 0;                              // last digit pass this launch ran (its histogram is still in LDS)
+    int last_pass = -1;                             // last digit pass this launch ran (its histogram is still in LDS)
+    int p_first = 1;
     if (threadIdx.x == 0) c_above = 0;
+    auto key_at = [&](int64_t i) -> uint64_t {
+        if constexpr (ONFLY) return masked_key(mode, eig[i], obj[i]);     // (both valid: see the launch)
+        else return keys[i];
+    };
+    if constexpr (ONFLY) {
+        const bool both = mode == TK_MODE_COMBAUTO;
+        mode = resolve_mode(mode, ws, sel);         // uniform over the grid: the strong count is final before this launch
+        const int64_t strong = strong_total(ws);
+        const int64_t cls = (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? n
+                            : (mode == TK_MODE_FEAS) ? ld_i64(&ws->counters[1]) : strong;
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            st_i64(&ws->mode, mode);
+            st_i64(&ws->counters[6], mode);
+            st_i64(&ws->counters[5], strong);      // for the host (round header)
+            st_i64(&ws->counters[0], cls);
+        }
+        if (both && mode == TK_MODE_COMBALL) {      // uniform over the grid
+            p_first = 0;
+            if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
+        } else {
+            resolve_digit(ws, 0, k, ws->hist[0], cls, &st1, blockIdx.x == 0, mode);
+        }
+        __syncthreads();
+    }
     TkState st;
-    for (int p = 1;; ++p) {
-        if (p > 1) {        // state[p] is published inside this launch
+    for (int p = p_first;; ++p) {
+        if (p > p_first) {        // state[p] is published inside this launch
             if (threadIdx.x == 0) {
                 int ok = 1;
                 uint32_t it = 0;
@@ -238,9 +272,13 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             __syncthreads();
             if (!go) return;
         }
-        st.prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
-        st.need = ld_i64(&ws->state[p].need);
-        st.stop = ld_i64(&ws->state[p].stop);
+        if (ONFLY && p == p_first) {
+            st = st1;
+        } else {
+            st.prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
+            st.need = ld_i64(&ws->state[p].need);
+            st.stop = ld_i64(&ws->state[p].stop);
+        }
         if (st.stop || st.need < 1 || p == 8) break;      // uniform over the grid
         hist[threadIdx.x] = 0;
         if (threadIdx.x == 0) c_above = 0;
@@ -250,17 +288,33 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)TK_UNROLL * TK_THREADS) {
             uint64_t key[TK_UNROLL];
             bool in[TK_UNROLL];
+            if (ONFLY && !cached) {      // uniform
+                // all 2 x TK_UNROLL score loads are issued before the first key is built (unconditional,
+                // from a clamped position: a load inside a branch is waited for on the spot)
+                double e[TK_UNROLL], o[TK_UNROLL];
 #pragma unroll
-            for (int u = 0; u < TK_UNROLL; ++u) {
-                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
-                in[u] = i < hi;
-                key[u] = !in[u] ? 0ull : (cached ? cache[i - lo] : keys[i]);
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                    in[u] = i < hi;
+                    const int64_t ic = in[u] ? i : hi - 1;
+                    e[u] = eig[ic];
+                    o[u] = obj[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) key[u] = in[u] ? masked_key(mode, e[u], o[u]) : 0ull;
+            } else {
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                    in[u] = i < hi;
+                    key[u] = !in[u] ? 0ull : (cached ? cache[i - lo] : keys[i]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < TK_UNROLL; ++u) {
                 const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
                 if (use_cache && !cached && in[u]) cache[i - lo] = key[u];
-                const uint64_t hi_part = key[u] >> (shift + 8), pre_part = st.prefix >> (shift + 8);
+                const uint64_t hi_part = p ? key[u] >> (shift + 8) : 0ull, pre_part = p ? st.prefix >> (shift + 8) : 0ull;
                 const bool match = in[u] && hi_part == pre_part;
                 above += in[u] && hi_part > pre_part;
                 hist_add(hist, (uint32_t)((key[u] >> shift) & 255), match);
@@ -271,7 +325,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         if ((threadIdx.x & 63) == 0 && above) atomicAdd(&c_above, above);
         __syncthreads();
         last_pass = p;
-        finish_pass(ws, p, k, hist, gridDim.x, true);
+        finish_pass(ws, p, k, hist, gridDim.x, true, p ? nullptr : ws->hist_alt);
         __syncthreads();
     }
     if (st.need < 1) return;                               // empty class: n_sel stays 0
@@ -280,7 +334,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     if (st.stop) {
         // early stop: every key >= T is wanted, in any order (the sort that follows orders them)
         uint32_t mine;
-        if (last_pass) {
+        if (last_pass >= 0) {
             // closed by the pass just run: this chunk's count is in its own histogram -- the keys beyond
             // the prefix' range plus the bins from the threshold bin up -- no counting pass over the keys
             const int shift = 8 * (7 - last_pass);
@@ -296,7 +350,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if (threadIdx.x == 0) c_gt = 0;
             __syncthreads();
             uint32_t my = 0;
-            for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) my += keys[i] >= T;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) my += key_at(i) >= T;
             for (int off = 32; off > 0; off >>= 1) my += __shfl_xor((int)my, off);
             if (lane == 0 && my) atomicAdd(&c_gt, my);
             __syncthreads();
@@ -312,7 +366,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         const int64_t base = (int64_t)slice;
         for (int64_t row = lo; row < hi; row += TK_THREADS) {
             const int64_t i = row + threadIdx.x;
-            const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : keys[i]) : 0ull;
+            const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : key_at(i)) : 0ull;
             const bool take = (i < hi) && key >= T;
             const unsigned long long m = __ballot(take);
             uint32_t wbase = 0;
@@ -332,7 +386,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     {
         uint32_t my_gt = 0, my_eq = 0;
         for (int64_t i = lo + threadIdx.x; i < hi; i += TK_THREADS) {
-            const uint64_t key = cached ? cache[i - lo] : keys[i];
+            const uint64_t key = cached ? cache[i - lo] : key_at(i);
             my_gt += (key > T);
             my_eq += (key == T);
         }
@@ -380,7 +434,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     if (!want_gt && !want_eq) return;     // uniform
     for (int64_t row = lo; row < hi; row += TK_THREADS) {
         const int64_t i = row + threadIdx.x;
-        const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : keys[i]) : 0ull;
+        const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : key_at(i)) : 0ull;
         if (i < hi && key > T) {
             const int64_t slot = base_gt + atomicAdd(&gt_local, 1u);
             sel_key[slot] = key;
@@ -773,6 +827,14 @@ int topk_begin(sdpcut_ctx *h, void **ws_out, uint64_t **keys_out)
 
 int64_t *topk_strong_counter(void *ws) { return ((TopkWs *)ws)->strong_rep; }
 
+// may the score kernels count the leading digit for a head of k entries (ScoreFuse, stage 3)?  Lists
+// that fit the sort buffers whole skip the radix passes altogether (tk_small_kernel).
+bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k)
+{
+    const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
+    return h->fused_tail && !h->coop_launch && k >= 1 && k <= TK_MAXK && h->N > maxk;
+}
+
 // Lists that fit the sort buffers whole (n <= 8192 -- most of the reference's BoxQP / QCQP instances)
 // need no radix passes: ONE workgroup builds the keys, counts the class and compacts its members;
 // the sort that follows orders all of them and emits the first k_eff.  Three launches instead of
@@ -824,10 +886,14 @@ __global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t 
 
 // Everything behind pass 0: the remaining digit passes, the compaction, the sort and the ranks.
 // n keys in h->d_key_a; k <= TK_MAXK; raw: see tk_mergerank_big_kernel (heads > TK_LDSK only).
+// onfly: pass 0 was counted by the score kernels and there are no keys (tk_refine_kernel<true>; eig / obj /
+// sel as for tk_keys_kernel).
 static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t n, int64_t k, double score_add,
                                     int64_t *d_idx_out, double *d_score_out, bool compacted, int raw, int64_t base,
-                                    int64_t emit_limit = TK_MAXK)
+                                    int64_t emit_limit = TK_MAXK, bool onfly = false, int64_t sel = 0,
+                                    const double *eig = nullptr, const double *obj = nullptr)
 {
+    if (onfly && (compacted || !h->fused_tail)) return sdpcut_fail(h, SDPCUT_ESTATE, "top-k select: no key pass to continue from");
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     if (!compacted) {
@@ -840,13 +906,17 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             const uint64_t *keys_arg = h->d_key_a;
             uint64_t *sk_arg = h->d_sel_key;
             uint32_t *si_arg = h->d_sel_idx;
-            int64_t n_arg = n, k_arg = k, chunk_arg = chunk;
-            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg};
-            if (h->coop_launch)
-                HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
+            int64_t n_arg = n, k_arg = k, chunk_arg = chunk, sel_arg = sel;
+            int mode_arg = mode;
+            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg, &mode_arg, &sel_arg, &eig, &obj};
+            if (onfly)      // (a measure the mode does not use is never looked at: any readable array of n doubles will do)
+                hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, nullptr, ws,
+                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig);
+            else if (h->coop_launch)
+                HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else
-                hipLaunchKernelGGL(tk_refine_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                                   h->d_sel_key, h->d_sel_idx);
+                hipLaunchKernelGGL(tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
+                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig, obj);
         } else {
             hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
             hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
@@ -892,20 +962,21 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
 }
 
 // stage 0: fresh selection; 1: the workspace has been handed out by topk_begin already (the score
-// kernels left their strong count in it); 2: the score kernels also ran pass 0 (keys, leading digit,
-// class counters).  mode TK_MODE_COMBAUTO: resolved by the first pass against `sel` (stage 1 only).
+// kernels left their strong count in it); 3: the score kernels also counted the leading digit of the keys
+// and the violated / positive candidates (ScoreFuse; topk_fuse_ok).  mode TK_MODE_COMBAUTO: resolved by
+// the first pass against `sel` (stages 1 and 3).
 int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                         double *d_score_out, const int64_t **d_counters_out, int stage, int64_t sel)
 {
     const int64_t n = h->N;
     if (k < 1 || k > TK_MAXK || n < 1) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k out of range");
-    if (mode == TK_MODE_COMBAUTO && stage != 1) return sdpcut_fail(h, SDPCUT_ESTATE, "top-k select: no strong count");
+    if (mode == TK_MODE_COMBAUTO && stage != 1 && stage != 3) return sdpcut_fail(h, SDPCUT_ESTATE, "top-k select: no strong count");
     int rc = 0;
     if (stage == 0) {
         rc = topk_begin(h, nullptr, nullptr);
         if (rc) return rc;
     }
-    const bool keys_done = stage == 2;
+    const bool keys_done = stage == 3;
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
     const double *eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
@@ -919,7 +990,8 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     } else if (!keys_done) {
         hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
     }
-    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base);
+    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base, TK_MAXK, keys_done, sel,
+                                  eig, obj);
     if (rc) return rc;
     if (d_counters_out) *d_counters_out = ws->counters;
     return 0;

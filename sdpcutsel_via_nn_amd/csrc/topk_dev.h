@@ -52,6 +52,8 @@ struct TopkWs {
     int64_t strong_rep[TK_SREP];   // strong candidates counted by the score kernels, replicated by workgroup
                                    // (same-address device atomics are serialised, see TK_HREP)
     uint32_t bar[8];               // one-shot grid barriers of the fused kernels (arrival counters)
+    uint32_t hist_alt[TK_HREP][256];   // leading-digit histogram of the COMBALL keys when the score kernels counted the
+                                       // STRONG keys into hist[0] and the device resolved the other regime
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -74,24 +76,51 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool acti
     const unsigned long long act = __ballot(active);
     if (!act) return;
     const int leader = __ffsll((long long)act) - 1;
-    const uint32_t lead_bin = (uint32_t)__shfl((int)bin, leader);
+    const uint32_t lead_bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);   // (leader is wave-uniform: v_readlane, not ds_bpermute)
     const unsigned long long same = __ballot(active && bin == lead_bin);
     if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lead_bin], (uint32_t)__popcll(same));
     if (active && bin != lead_bin) atomicAdd(&hist[bin], 1u);
 }
 
+// The same for digits that take only a handful of values across a wave (the LEADING digit of the keys:
+// sign and high exponent bits -- a few bins hold everything): rounds of wave aggregation, so that a wave
+// issues one LDS atomic per distinct bin instead of one per lane into the same few cells.
+// (Device atomics straight into the global histogram, one per distinct bin and strip, were measured: +15 us
+// on the score kernel -- its next loads queue behind them in the memory pipeline.)
+__device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool active)
+{
+    unsigned long long rem = __ballot(active);
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll 1
+    for (int it = 0; it < 4 && rem; ++it) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t lead_bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == lead_bin);
+        if (lane == leader) atomicAdd(&hist[lead_bin], (uint32_t)__popcll(same));
+        rem &= ~same;
+    }
+    if ((rem >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+}
+
 // Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].
-static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
+// row / cls_known / mine / publish: a pass 0 that the score kernels counted is resolved by EVERY block of
+// the selection for itself -- state[1] goes to *mine (LDS); only the block with publish = true also
+// stores the global copy (the resolving block of pass 1 reads it; 256 blocks storing the same words
+// would queue up on one cache line).
+static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k, const uint32_t (*row)[256] = nullptr,
+                                     int64_t cls_known = -1, TkState *mine = nullptr, bool publish = true,
+                                     int mode_known = 0)
 {
     __shared__ uint32_t suf[TK_THREADS];
     const int t = threadIdx.x;
     int64_t need;
     uint64_t prefix;
+    if (!row) row = ws->hist[p];
     if (p == 0) {
-        const int64_t cls = ld_i64(&ws->counters[0]);
+        const int64_t cls = cls_known >= 0 ? cls_known : ld_i64(&ws->counters[0]);
         need = k < cls ? k : cls;
         prefix = 0;
-        if (t == 0) st_i64(&ws->counters[3], need);      // k_eff for the later passes and kernels
+        if (t == 0 && publish) st_i64(&ws->counters[3], need);      // k_eff for the later passes and kernels
     } else {
         need = ld_i64(&ws->state[p].need);       // written by the previous launch, or by another block of this one
         prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
@@ -99,14 +128,21 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
     {
         uint32_t acc = 0;
 #pragma unroll
-        for (int r = 0; r < TK_HREP; ++r) acc += ld_u32(&ws->hist[p][r][t]);
+        for (int r = 0; r < TK_HREP; ++r) acc += ld_u32(&row[r][t]);
         suf[t] = acc;
     }
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {     // suffix sums S[t] = sum_{b >= t} hist[b]
-        const uint32_t v = (t + off < 256) ? suf[t + off] : 0u;
+    {   // suffix sums S[t] = sum_{b >= t} hist[b]: within each wave by shuffles, then the totals of the waves above
+        __shared__ uint32_t wtot[TK_THREADS / 64];
+        const int ln = t & 63, wv = t >> 6;
+        uint32_t v = suf[t];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_down((int)v, off);
+            if (ln + off < 64) v += o;
+        }
+        if (ln == 0) wtot[wv] = v;
         __syncthreads();
-        suf[t] += v;
+        for (int w = wv + 1; w < TK_THREADS / 64; ++w) v += wtot[w];
+        suf[t] = v;
         __syncthreads();
     }
     const int64_t here = suf[t], above = (t < 255) ? suf[t + 1] : 0;
@@ -118,29 +154,36 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
             // and let the final sort put the wanted k_eff first.  With 10^6 spread-out scores this
             // happens after 2-3 digits; masses of equal keys keep the passes going to the last digit,
             // where ties are cut by index as before.
-            const int64_t k_eff = ld_i64(&ws->counters[3]);
+            const int64_t k_eff = (p == 0) ? need : ld_i64(&ws->counters[3]);
             const int64_t in_bin = here - above;
             const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;     // what the sort buffers of this head hold
             const int64_t superset = (p == 0 ? need : k_eff) - (need - above) + in_bin;
             // Mode COMBALL cannot cut a group of equal keys by index (their order is by obj_improve):
             // at the last digit it either takes the whole group too, or declares the selection void
             // (counters[4]) and the host sorts the full list.
-            const bool comball = ld_i64(&ws->mode) == TK_MODE_COMBALL;
+            const bool comball = (mode_known ? (int64_t)mode_known : ld_i64(&ws->mode)) == TK_MODE_COMBALL;
             if (p == 7 && comball && in_bin > need - above && superset > maxk) st_i64(&ws->counters[4], 2);
             if ((p < 7 || comball) && superset <= maxk) {
-                for (int qq = p + 1; qq <= 8; ++qq) {
+                if (mine) { mine->prefix = pre; mine->need = in_bin; mine->stop = 1; }
+                for (int qq = p + 1; qq <= 8 && publish; ++qq) {
                     st_i64((int64_t *)&ws->state[qq].prefix, (int64_t)pre);
                     st_i64(&ws->state[qq].need, in_bin);   // every key equal to the bin's lowest value, if any
                     st_i64(&ws->state[qq].stop, 1);
                 }
             } else {
-                st_i64((int64_t *)&ws->state[p + 1].prefix, (int64_t)pre);
-                st_i64(&ws->state[p + 1].need, need - above);
+                if (mine) { mine->prefix = pre; mine->need = need - above; mine->stop = 0; }
+                if (publish) {
+                    st_i64((int64_t *)&ws->state[p + 1].prefix, (int64_t)pre);
+                    st_i64(&ws->state[p + 1].need, need - above);
+                }
             }
         }
     } else if (t == 0) {
-        st_i64((int64_t *)&ws->state[p + 1].prefix, 0);
-        st_i64(&ws->state[p + 1].need, 0);
+        if (mine) { mine->prefix = 0; mine->need = 0; mine->stop = 0; }
+        if (publish) {
+            st_i64((int64_t *)&ws->state[p + 1].prefix, 0);
+            st_i64(&ws->state[p + 1].need, 0);
+        }
     }
 }
 
@@ -152,10 +195,11 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k)
 // with the score kernel's 24 MB of output in flight that cost ~25 us over the 2048 blocks; a
 // __threadfence() by all threads ~30 us per pass.)  The last block acquires once.
 static __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t *hist, uint32_t total_blocks,
-                                   bool publish = false)
+                                   bool publish = false, uint32_t (*row)[256] = nullptr)
 {
     __shared__ uint32_t ticket;
-    if (hist[threadIdx.x]) atomicAdd(&ws->hist[p][blockIdx.x % TK_HREP][threadIdx.x], hist[threadIdx.x]);
+    if (!row) row = ws->hist[p];
+    if (hist[threadIdx.x]) atomicAdd(&row[blockIdx.x % TK_HREP][threadIdx.x], hist[threadIdx.x]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -167,7 +211,7 @@ static __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        resolve_digit(ws, p, k);
+        resolve_digit(ws, p, k, row);
         if (publish) {      // grid barrier of tk_hist_rest_kernel: state[p+1] is complete
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -37,6 +37,13 @@ class DeviceOps(object):
         # collectives torch enqueues are then ordered without host synchronisation
         scorer.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
+    def ensure_scored(self, strat):
+        """score what strategy ``strat`` ranks by and the current point does not have yet"""
+        need = _capi.EIG if strat == 1 else _capi.NN if strat == 2 else (_capi.EIG | _capi.NN)
+        have = self.scorer.get_stat(_capi.STAT_SCORED)
+        if (have & need) != need:
+            self.scorer.score(need & ~have)
+
     def local_head(self, strat, sel_size, count, want_secondary=False):
         """-> (scores[count] fp64, ids[count] int64, secondary[count] or None, n_total, counters);
         device tensors padded with (-inf, PAD, -inf).  secondary = obj_improve of each entry."""
@@ -206,7 +213,11 @@ class ShardedSelector(object):
         Common regime (strategies 1 and 2; strategy 4 with at least sel_size strong candidates
         overall): ONE collective and ONE host synchronisation per round -- the shard's head and
         its counters are packed on the device, all-gathered, merged and turned into rows by
-        two library calls (shard_head / shard_finish).  Otherwise :meth:`select` runs."""
+        two library calls (shard_head / shard_finish).  Otherwise :meth:`select` runs.
+
+        The shard need not be scored beforehand: shard_head scores what the current point lacks (and,
+        when nothing has been scored yet, lets the score kernels prepare the selection's first radix
+        digit); :meth:`select` on its own expects the scores (``ops.ensure_scored``)."""
         if strat not in (1, 2, 4):
             raise ValueError("strategy must be 1, 2 or 4")
         sel = min(int(sel_size), self.n_global)
@@ -235,6 +246,8 @@ class ShardedSelector(object):
                     res.update(mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
                                rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine])
                 return res
+        if hasattr(ops, "ensure_scored"):
+            ops.ensure_scored(strat)
         res = self.select(strat, sel_size)
         ids = res["ids"].cpu().numpy()
         mine, lam, coef, rhs, ks = ops.rows_of(ids)

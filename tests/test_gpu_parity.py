@@ -728,17 +728,17 @@ def test_select_round_equals_separate_calls(full_c2, scorer, strat):
         assert rc == 0 and n_out.value == w and n_tot.value == total and ns.value == new_strat
         assert np.array_equal(o_idx[:w], ids) and np.array_equal(o_coef[:w], r["coef"]) and np.array_equal(o_ks[:w], ks)
     assert scorer.select_round(strat, 0)["idx"].size == 0
-    # optional fusion of the selection's key pass into the score kernel: same results
-    scorer.set_option(_capi.OPT_FUSE_KEYS, 1)
+    # without the leading-digit histograms from the score kernels (the selection runs its own key pass): same results
+    scorer.set_option(_capi.OPT_FUSE_KEYS, 0)
     try:
         for sel in (5000, 33):
-            scorer.set_point(wl["vars_values"])          # clears the scored flags -> fused scoring runs
+            scorer.set_point(wl["vars_values"])          # clears the scored flags -> the round scores again
             v = scorer.select_round(strat, sel)
             ids, score, total, new_strat, cnt = scorer.rank(strat, sel, max_out=sel)
             assert np.array_equal(v["idx"], ids) and np.array_equal(v["score"], score)
             assert v["n_total"] == total and v["new_strat"] == new_strat and v["counters"] == cnt
     finally:
-        scorer.set_option(_capi.OPT_FUSE_KEYS, 0)
+        scorer.set_option(_capi.OPT_FUSE_KEYS, 1)
 
 
 def test_select_round_general_regime(full_c2, scorer):
