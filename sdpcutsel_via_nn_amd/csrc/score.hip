@@ -547,6 +547,29 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         wave_lds_sync();
         PHASE_MARK(3);
 
+        // Weight fragments requested one stage ahead of their use (SDPCUT_XPREFETCH): the input layer's
+        // tile t+1 while tile t computes, the first fragments of a hidden layer before the last tansig of
+        // the layer in front of it, the first input tile of the next pass before the output layer.
+        // Measured: the 2-variable kernel gains 1.5 % (0.399 -> 0.393 ms), the 3-variable one loses 0.6 %
+        // (its other wave already covers the L2 round trips at the stage boundaries; 5 more live
+        // registers cost more), the 4/5-variable ones have no registers left (spills): on for K = 2 only.
+#ifndef SDPCUT_XPREFETCH
+#define SDPCUT_XPREFETCH 1
+#endif
+#ifndef SDPCUT_XPREFETCH_MAXK
+#define SDPCUT_XPREFETCH_MAXK 2
+#endif
+#ifndef SDPCUT_RING_DEPTH
+#define SDPCUT_RING_DEPTH 4
+#endif
+        constexpr int RD = SDPCUT_RING_DEPTH;
+        constexpr bool XP = SDPCUT_XPREFETCH && K <= SDPCUT_XPREFETCH_MAXK;
+        double a_in[S0];              // input-layer fragments of the tile about to run
+        double pre[RD];               // head of the next hidden layer's fragment stream
+        if constexpr (XP) {
+#pragma unroll
+            for (int s = 0; s < S0; ++s) a_in[s] = net.wfrag[s * 64 + lane];
+        }
 #pragma unroll 1
         for (int pass = 0; pass < NPASS; ++pass) {
             // B fragments of the input layer: B[k = 4s + q][col = candidate]
@@ -566,9 +589,20 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 for (int r = 0; r < 4; ++r) bias[r] = BIAS_AT(16 * t + 4 * r + q);
 #pragma unroll
                 for (int j = 0; j < J; ++j) cur[t][j] = bias;
+                double a_nx[S0];
+                if constexpr (XP) {
+                    if (t + 1 < TM) {
+#pragma unroll
+                        for (int s = 0; s < S0; ++s) a_nx[s] = WFRAG_AT(((t + 1) * S0 + s) * 64 + lane);
+                    } else if (NH > 1) {      // the first hidden layer's stream starts behind the T input tiles
+#pragma unroll
+                        for (int g = 0; g < RD - 1; ++g) pre[g] = WFRAG_AT((T * S0 + g) * 64 + lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int s = 0; s < S0; ++s) {
-                    const double a = WFRAG_AT((t * S0 + s) * 64 + lane);
+                    const double a = XP ? a_in[s] : WFRAG_AT((t * S0 + s) * 64 + lane);
 #pragma unroll
                     for (int j = 0; j < J; ++j)
                         cur[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bin[s][j], cur[t][j], 0, 0, 0);
@@ -576,6 +610,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                 for (int j = 0; j < J; ++j) cur[t][j] = tansig_tile<H, CLAMP>(cur[t][j], t);
                 __builtin_amdgcn_sched_barrier(0);
+                if (XP && t + 1 < TM) {
+#pragma unroll
+                    for (int s = 0; s < S0; ++s) a_in[s] = a_nx[s];
+                }
             }
             if constexpr (NT > 0) {
                 double ts[J][NT ? NT : 1];
@@ -605,13 +643,11 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                 // alone hipcc loads each fragment right before its two MFMAs and waits vmcnt(0)
                 // (an L2 round trip per 128 MFMA cycles, the dominant stall in the first PMC run):
                 // a ring of RD fragments keeps RD-1 loads in flight; the sched_barriers pin the order.
-#ifndef SDPCUT_RING_DEPTH
-#define SDPCUT_RING_DEPTH 4
-#endif
-                constexpr int RD = SDPCUT_RING_DEPTH, NG = TM * SH;
+                constexpr int NG = TM * SH;
+                static_assert(NG >= RD - 1, "fragment stream shorter than the ring");
                 double ring[RD];
 #pragma unroll
-                for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = WFRAG_AT(g * 64 + lane);
+                for (int g = 0; g < RD - 1 && g < NG; ++g) ring[g] = XP ? pre[g] : WFRAG_AT(g * 64 + lane);
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
                     d4 bias;
@@ -623,6 +659,17 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                     for (int s = 0; s < SH; ++s) {
                         const int g = t * SH + s;
                         if (g + RD - 1 < NG) ring[(g + RD - 1) % RD] = WFRAG_AT((g + RD - 1) * 64 + lane);
+                        if (XP && g == NG - 1) {
+                            // the stage behind this layer: the next hidden layer's head, or -- behind the last
+                            // one -- the first input tile of the next pass
+                            if (l + 1 < NH) {
+#pragma unroll
+                                for (int gg = 0; gg < RD - 1; ++gg) pre[gg] = WFRAG_AT((T * SH + gg) * 64 + lane);
+                            } else {
+#pragma unroll
+                                for (int ss = 0; ss < S0; ++ss) a_in[ss] = net.wfrag[ss * 64 + lane];
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int j = 0; j < J; ++j)

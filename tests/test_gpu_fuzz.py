@@ -112,3 +112,55 @@ def test_random_instances_against_the_oracle(lib, oracle, seed):
             sc.score(_capi.EIG | _capi.NN)
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_rounds_that_score_for_themselves_against_the_oracle(lib, oracle, seed):
+    """sdpcut_select_round on a fresh point (nothing scored): the score kernels count the leading radix digit
+    of the selection keys and the selection builds its keys from the scores (no key pass).  Lists longer than
+    the sort buffers, every strategy, both regimes of the combined one, generic and tie-heavy points, mixed
+    candidate sizes; against the oracle's ranking of the device's own scores and against the unfused round."""
+    from sdpcutsel_via_nn_amd import _capi, networks
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(8, 41))
+    N = int(rng.choice([8193, 9001, 20000, 65536, 150001, 300000]))
+    kinds = [k for k in (2, 3, 4, 5) if rng.uniform() < 0.5] or [3]
+    Q, sets, ks = _instance(rng, n, N, kinds)
+    vv = _point(rng, n, rng.choice(["gen", "gen", "mid", "psd"]))
+    sc = lib.Scorer(0)
+    try:
+        for k in range(2, 6):
+            sc.set_network(k, *networks.load_network(k))
+        sc.set_instance(n, Q)
+        base = int(rng.choice([0, 11, 10 ** 10]))
+        sc.set_candidates(sets, ks, global_base=base)
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        n_strong = int(((obj > 0) & (eig < -1e-15)).sum())
+        for strat in (1, 2, 4):
+            sels = {1, 37, 5000, 8192, int(rng.integers(1, 8193))}
+            if strat == 4 and n_strong > 2:
+                sels |= {max(n_strong - 1, 1), min(n_strong + 1, 8192)}      # either side of the regime switch
+            for sel in sorted(sels):
+                order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, sel)
+                w = min(sel, order.shape[0])
+                voids = []
+                for fuse in (1, 0):
+                    sc.set_option(_capi.OPT_FUSE_KEYS, fuse)
+                    sc.set_point(vv)                       # nothing scored: the round scores for itself
+                    before = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)
+                    r = sc.select_round(strat, sel)
+                    voids.append(sc.get_stat(_capi.STAT_SELECT_FALLBACKS) - before)
+                    assert np.array_equal(r["idx"], order[:w] + base), (seed, strat, sel, fuse)
+                    assert np.array_equal(r["score"], ref_score[:w] + 0.0), (seed, strat, sel, fuse)
+                    assert r["n_total"] == order.shape[0] and r["new_strat"] == ref_strat, (seed, strat, sel, fuse)
+                    if strat == 4:
+                        assert r["counters"]["strong"] == ref_cnt["strong"] and r["counters"]["violated"] == ref_cnt["violated"]
+                    if w:
+                        assert np.abs(r["lam"] - eig[order[:w]]).max() <= 1e-14
+                # a selection may declare itself void (a tie group of the every-entry-visited regime that the sort
+                # buffers cannot hold: the full-sort path answers) -- but the same ones in both variants
+                assert voids[0] == voids[1], (seed, strat, sel, voids)
+    finally:
+        sc.close()

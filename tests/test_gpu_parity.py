@@ -640,6 +640,13 @@ def test_topk_select_with_masses_of_equal_keys_full_size(full_c2, scorer, oracle
             r = scorer.select_round(strat, 5000, copy=False)
             order, ref_score, ref_strat, _ = oracle.rank_arrays(strat, obj, eig, 5000)
             assert np.array_equal(r["idx"], order[:5000]) and np.array_equal(r["score"], ref_score[:5000] + 0.0)
+            # the same round scoring for itself: the score kernel counts the leading digit, the selection starts
+            # at the second one and builds its keys from the scores (all eight digits + the cut by index here)
+            scorer.set_point(vv)
+            r = scorer.select_round(strat, 5000, copy=False)
+            assert np.array_equal(r["idx"], order[:5000]) and np.array_equal(r["score"], ref_score[:5000] + 0.0)
+            assert r["new_strat"] == ref_strat
+            scorer.score(_capi.EIG | _capi.NN)
     finally:
         scorer.set_point(wl["vars_values"])
         scorer.score(_capi.EIG | _capi.NN)
