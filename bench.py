@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
+    ap.add_argument("--two-calls", action="store_true", help="A/B: sdpcut_set_point + sdpcut_select_round_view instead of sdpcut_round_view")
     ap.add_argument("--coop", action="store_true", help="A/B: cooperative launch of the fused selection kernel (+20 us per round)")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     ap.add_argument("--k", type=int, choices=[2, 3, 4, 5], default=None, help="candidate size (default: the config's, 3)")
@@ -249,15 +250,19 @@ def main():
             counter[0] += 1
             if timed:
                 sc.set_option(_capi.OPT_TIMING, 1)
-            if d_vars is not None:
-                sc.set_point_device(d_vars.data_ptr())
-            else:
-                sc.set_point(vv_host)          # host -> device: part of every real round (41 KB at n = 100, 4 MB at n = 1000)
-            if sel is None:
-                # one C-ABI call: score (eig + NN) -> combined ranking -> cut rows of the head -> results written
-                # by the device into the handle's pinned host block (copy=False hands out views of it)
+            if sel is None and d_vars is None and not args.two_calls:
+                # one C-ABI call: LP point host -> device (41 KB at n = 100, 4 MB at n = 1000; part of every real
+                # round) -> score (eig + NN) -> combined ranking -> cut rows of the head -> results written by the
+                # device into the handle's pinned host block (copy=False hands out views of it)
+                res = sc.select_round(4, SEL, copy=False, point=vv_host)
+            elif sel is None:
+                if d_vars is not None:
+                    sc.set_point_device(d_vars.data_ptr())
+                else:
+                    sc.set_point(vv_host)
                 res = sc.select_round(4, SEL, copy=False)
             else:
+                sc.set_point(vv_host)
                 # score the shard + packed head record (one call) -> ONE all-gather (RCCL) -> replicated merge ->
                 # each rank generates the rows of its own candidates -> one D2H, one host sync
                 res = sel.select_round(4, SEL)

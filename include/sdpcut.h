@@ -257,6 +257,16 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
                              int64_t *n_total, int32_t *new_strat, int64_t *counters);
 
 /*
+ * One cutting-plane round from the LP point to the cut rows in ONE call: sdpcut_set_point(vars_values)
+ * followed by sdpcut_select_round_view(...) -- what the separation step of cut_select_qp.py:165-182
+ * does between two LP solves.  Same results as the two calls; the point transfer and the score kernel are
+ * enqueued back to back and the caller crosses the FFI once per round.
+ */
+int sdpcut_round_view(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, int32_t coef_ld,
+                      const void **block, int64_t *cap_out, int64_t *n_out,
+                      int64_t *n_total, int32_t *new_strat, int64_t *counters);
+
+/*
  * The same round over candidate shards (one handle per GPU, SURVEY 8 e): the two device-side
  * halves around the single all-gather the caller performs (torch.distributed / RCCL).
  *

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sdpcut_cut_rows": [_vp, _c.c_int64, _i64p, _dp, _dp, _dp, _i64p, _i32p],
     "sdpcut_select_round": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _i64p, _dp, _dp, _dp, _dp, _i32p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_select_round_view": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
+    "sdpcut_round_view": [_vp, _dp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
@@ -320,9 +321,12 @@ class Scorer(object):
                                               _ptr(rhs, _dp), _ptr(cols, _i64p), _ptr(ks, _i32p)))
         return lam, coef, rhs, cols, ks
 
-    def select_round(self, strat, sel_size, copy=True):
+    def select_round(self, strat, sel_size, copy=True, point=None):
         """score (if needed) + rank + cut rows of the head in one call
         -> dict(idx, score, lam, coef, rhs, ks, n_total, new_strat, counters).
+
+        point: the LP point [X packed | x] of this round -- set_point and the round in ONE library call
+        (sdpcut_round_view).
 
         The device writes the results into a pinned host block owned by the handle
         (sdpcut_select_round_view).  copy=False returns numpy views of that block: no host copy
@@ -330,9 +334,18 @@ class Scorer(object):
         ld = self.row_len
         block, cap, n_out, n_total, new_strat = _c.c_void_p(), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
         cnt = np.zeros(4, dtype=np.int64)
-        self._check(self._lib.sdpcut_select_round_view(
-            self._h, int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
-            ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+        if point is not None:
+            vv = _f64(point)
+            n = self.nb_vars
+            if vv.shape != (n * (n + 1) // 2 + n,):
+                raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
+            self._check(self._lib.sdpcut_round_view(
+                self._h, _ptr(vv, _dp), int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
+                ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+        else:
+            self._check(self._lib.sdpcut_select_round_view(
+                self._h, int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
+                ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
         w, c = int(n_out.value), int(cap.value)
         if block.value and c:
             key = (block.value, c, ld)

@@ -777,6 +777,15 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     return SDPCUT_OK;
 }
 
+int sdpcut_round_view(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, int32_t coef_ld,
+                      const void **block, int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat,
+                      int64_t *counters)
+{
+    int rc = sdpcut_set_point(h, vars_values);
+    if (rc) return rc;
+    return sdpcut_select_round_view(h, strat, sel_size, coef_ld, block, cap_out, n_out, n_total, new_strat, counters);
+}
+
 int sdpcut_select_round(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, int64_t *idx_out,
                         double *score_out, double *lam_min, double *coef, double *rhs, int32_t *ks, int64_t *n_out,
                         int64_t *n_total, int32_t *new_strat, int64_t *counters)

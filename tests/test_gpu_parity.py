@@ -735,6 +735,14 @@ def test_select_round_equals_separate_calls(full_c2, scorer, strat):
         assert rc == 0 and n_out.value == w and n_tot.value == total and ns.value == new_strat
         assert np.array_equal(o_idx[:w], ids) and np.array_equal(o_coef[:w], r["coef"]) and np.array_equal(o_ks[:w], ks)
     assert scorer.select_round(strat, 0)["idx"].size == 0
+    # the point handed over with the round (sdpcut_round_view: one library call per round)
+    v = scorer.select_round(strat, 5000, point=wl["vars_values"])
+    ids, score, total, new_strat, cnt = scorer.rank(strat, 5000, max_out=5000)
+    assert np.array_equal(v["idx"], ids) and np.array_equal(v["score"], score) and v["counters"] == cnt
+    lam, coef, rhs, cols, ks = scorer.cut_rows(ids)
+    assert np.array_equal(v["lam"], lam) and np.array_equal(v["coef"], coef[:, :9]) and np.array_equal(v["rhs"], rhs)
+    with pytest.raises(ValueError):
+        scorer.select_round(strat, 5000, point=wl["vars_values"][:-1])
     # without the leading-digit histograms from the score kernels (the selection runs its own key pass): same results
     scorer.set_option(_capi.OPT_FUSE_KEYS, 0)
     try:
