@@ -38,8 +38,16 @@ FLOPS_PER_CAND = {2: 17152, 3: 11000, 4: 11500, 5: 27264}     # MLP mul+add only
 BYTES_PER_CAND = {2: 24, 3: 28, 4: 32, 5: 36}                 # index set in, two fp64 scores out
 FP64_PEAK_TFLOPS = 78.6                                       # MI355X fp64 matrix = vector peak
 HBM_PEAK_GBS = 8000.0
-KERNEL_NAMES = {2: "score_mfma_kernel<2, 64, 3, false, false>", 3: "score_mfma_kernel<3, 50, 3, false, false>",
-                4: "score_mfma_kernel<4, 50, 3, false, false>", 5: "score_mfma_kernel<5, 64, 4, false, false>"}
+KERNEL_SHAPES = {2: "2, 64, 3", 3: "3, 50, 3", 4: "4, 50, 3", 5: "5, 64, 4"}     # K, hidden width, hidden layers
+
+
+def kernel_name(k, counts_digit):
+    """rocprofv3's name of the MFMA scoring kernel of size k: <K, H, NH, FUSE, CLAMP>; FUSE = 3 (TK_MODE_STRONG) when the
+    kernel also counts the leading digit of the combined strategy's selection keys (the default round), CLAMP = false for
+    the shipped networks (pre-activations provably bounded)"""
+    return "score_mfma_kernel<%s, %d, false>" % (KERNEL_SHAPES[k], 3 if counts_digit else 0)
+
+
 CONFIGS = {
     "c2": dict(nb_vars=100, k=3, total=None, per_gpu=10 ** 6, scaling="weak",
                text="configs[1]: synthetic n=100 dense X, 1e6 random 3-var index sets per GPU, eig + neural_net_3D "
@@ -128,11 +136,11 @@ class _StdoutToStderr(object):
         os.close(self._saved)
 
 
-def roofline(k, n_per_launch, kernel_ms, traffic):
+def roofline(k, n_per_launch, kernel_ms, traffic, counts_digit=True):
     tflops = FLOPS_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e12
     gbs = BYTES_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e9
     return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-            "traffic": traffic, "kernel": KERNEL_NAMES[k], "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
+            "traffic": traffic, "kernel": kernel_name(k, counts_digit), "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
             "flops_per_candidate": FLOPS_PER_CAND[k], "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
             "bytes_per_candidate": BYTES_PER_CAND[k]}
 
@@ -323,7 +331,7 @@ def main():
             "config": {"workload": cfg["text"], "config": args.config, "candidates_per_gpu": n_local, "nb_vars": nb_vars, "k": K,
                        "sel_size": SEL, "kernel": args.kernel, "strategy": 4,
                        "bracket": "device point -> host results" if args.device_point else "host point -> host results"},
-            "roofline": roofline(K, n_local, k_ms, traffic),
+            "roofline": roofline(K, n_local, k_ms, traffic, counts_digit=not args.no_fuse_keys),
         }
         out["roofline"]["kernel_ms_samples"] = len(kernel_ms)
         out["config"]["selection_fallbacks"] = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)       # rounds answered by the full-sort path
@@ -347,7 +355,7 @@ def main():
                     st2()
                 torch.cuda.synchronize()
                 d2 = time.perf_counter() - t1
-                r2 = roofline(k2, n_local, float(np.mean(ms2)), None)
+                r2 = roofline(k2, n_local, float(np.mean(ms2)), None, counts_digit=not args.no_fuse_keys)
                 sec["k%d" % k2] = {"value": n_local * n2 / d2, "unit": "candidates/s", "ms_per_step": d2 / n2 * 1e3, "steps": n2,
                                    "kernel_ms": r2["kernel_ms"], "roofline_frac": r2["frac"], "achieved_TFLOPs": r2["achieved"]}
                 s2.close()

@@ -41,19 +41,24 @@ def main():
     t_end = time.time() + budget
     while time.time() < t_end:
         p = int(rng.integers(0, len(points)))
+        own = bool(rng.integers(0, 2))      # the heads score their shards themselves (nothing scored when they are asked)
         for ops in opss:
             ops.scorer.set_point(points[p])
-            ops.scorer.score(_capi.EIG | _capi.NN)
+            if not own:
+                ops.scorer.score(_capi.EIG | _capi.NN)
         for _ in range(10):
             strat, code = [(1, 1), (2, 2), (4, _capi.PART_STRONG)][int(rng.integers(0, 3))]
             sel = int(rng.choice([1, 29, 777, 5000, 8192]))
+            if own:
+                for ops in opss:
+                    ops.scorer.set_point(points[p])
             allrec = torch.cat([ops.shard_head(code, sel) for ops in opss])
             heads = []
             for r, ops in enumerate(opss):
                 out = ops.shard_finish(len(sizes), sel, allrec, sel)
                 got = {k: np.array(v, copy=True) for k, v in out.items() if isinstance(v, np.ndarray)}
                 heads.append((got["idx"], got["score"]))
-                key = (p, strat, sel, r)
+                key = (p, strat, sel, r, own)
                 if key not in first:
                     first[key] = got
                     continue
