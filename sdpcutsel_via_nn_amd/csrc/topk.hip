@@ -233,12 +233,26 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         if constexpr (ONFLY) return masked_key(mode, eig[i], obj[i]);     // (both valid: see the launch)
         else return keys[i];
     };
+    // ONFLY: the scores of the first batch are requested before digit 0 is resolved (they do not depend on it)
+    double pre_e[TK_UNROLL], pre_o[TK_UNROLL];
     if constexpr (ONFLY) {
+        if (lo < hi) {
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = lo + (int64_t)u * TK_THREADS + threadIdx.x;
+                const int64_t ic = i < hi ? i : hi - 1;
+                pre_e[u] = eig[ic];
+                pre_o[u] = obj[ic];
+            }
+        }
         const bool both = mode == TK_MODE_COMBAUTO;
-        mode = resolve_mode(mode, ws, sel);         // uniform over the grid: the strong count is final before this launch
-        const int64_t strong = strong_total(ws);
+        // (everything read here was written by earlier launches: plain loads)
+        int64_t strong = 0;
+#pragma unroll
+        for (int r = 0; r < TK_SREP; ++r) strong += ws->strong_rep[r];
+        if (both) mode = strong >= sel ? TK_MODE_STRONG : TK_MODE_COMBALL;      // uniform over the grid
         const int64_t cls = (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? n
-                            : (mode == TK_MODE_FEAS) ? ld_i64(&ws->counters[1]) : strong;
+                            : (mode == TK_MODE_FEAS) ? ws->counters[1] : strong;
         if (threadIdx.x == 0 && blockIdx.x == 0) {
             st_i64(&ws->mode, mode);
             st_i64(&ws->counters[6], mode);
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             p_first = 0;
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
-            resolve_digit(ws, 0, k, ws->hist[0], cls, &st1, blockIdx.x == 0, mode);
+            resolve_digit(ws, 0, k, ws->hist[0], cls, &st1, blockIdx.x == 0, mode, true);
         }
         __syncthreads();
     }
@@ -292,13 +306,22 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 // all 2 x TK_UNROLL score loads are issued before the first key is built (unconditional,
                 // from a clamped position: a load inside a branch is waited for on the spot)
                 double e[TK_UNROLL], o[TK_UNROLL];
+                if (r0 == lo) {      // uniform: the batch requested at the top of the kernel
 #pragma unroll
-                for (int u = 0; u < TK_UNROLL; ++u) {
-                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
-                    in[u] = i < hi;
-                    const int64_t ic = in[u] ? i : hi - 1;
-                    e[u] = eig[ic];
-                    o[u] = obj[ic];
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        in[u] = lo + (int64_t)u * TK_THREADS + threadIdx.x < hi;
+                        e[u] = pre_e[u];
+                        o[u] = pre_o[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                        in[u] = i < hi;
+                        const int64_t ic = in[u] ? i : hi - 1;
+                        e[u] = eig[ic];
+                        o[u] = obj[ic];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < TK_UNROLL; ++u) key[u] = in[u] ? masked_key(mode, e[u], o[u]) : 0ull;
@@ -364,18 +387,43 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         }
         __syncthreads();
         const int64_t base = (int64_t)slice;
-        for (int64_t row = lo; row < hi; row += TK_THREADS) {
-            const int64_t i = row + threadIdx.x;
-            const uint64_t key = (i < hi) ? (cached ? cache[i - lo] : key_at(i)) : 0ull;
-            const bool take = (i < hi) && key >= T;
-            const unsigned long long m = __ballot(take);
-            uint32_t wbase = 0;
-            if (lane == 0 && m) wbase = atomicAdd(&gt_local, (uint32_t)__popcll(m));
-            wbase = (uint32_t)__shfl((int)wbase, 0);
-            if (take) {
-                const int64_t slot = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                sel_key[slot] = key;
-                sel_idx[slot] = (uint32_t)i;
+        // (rows in batches of TK_UNROLL with all their loads issued first: a chunk that does not fit the LDS cache
+        // -- 4.9e4 keys per workgroup on a 1.25e7-candidate shard -- would otherwise pay a trip to HBM per row)
+        for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)TK_UNROLL * TK_THREADS) {
+            uint64_t kk[TK_UNROLL];
+            if (ONFLY && !cached) {      // uniform
+                double e[TK_UNROLL], o[TK_UNROLL];
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                    const int64_t ic = i < hi ? i : hi - 1;
+                    e[u] = eig[ic];
+                    o[u] = obj[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) kk[u] = masked_key(mode, e[u], o[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                    kk[u] = (i < hi) ? (cached ? cache[i - lo] : keys[i]) : 0ull;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TK_UNROLL; ++u) {
+                const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                if (r0 + (int64_t)u * TK_THREADS >= hi) break;      // uniform
+                const uint64_t key = kk[u];
+                const bool take = (i < hi) && key >= T;
+                const unsigned long long m = __ballot(take);
+                uint32_t wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&gt_local, (uint32_t)__popcll(m));
+                wbase = (uint32_t)__shfl((int)wbase, 0);
+                if (take) {
+                    const int64_t slot = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    sel_key[slot] = key;
+                    sel_idx[slot] = (uint32_t)i;
+                }
             }
         }
         return;

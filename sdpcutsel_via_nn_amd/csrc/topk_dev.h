@@ -109,7 +109,7 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
 // would queue up on one cache line).
 static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k, const uint32_t (*row)[256] = nullptr,
                                      int64_t cls_known = -1, TkState *mine = nullptr, bool publish = true,
-                                     int mode_known = 0)
+                                     int mode_known = 0, bool plain = false)
 {
     __shared__ uint32_t suf[TK_THREADS];
     const int t = threadIdx.x;
@@ -128,7 +128,7 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k, const uint32_
     {
         uint32_t acc = 0;
 #pragma unroll
-        for (int r = 0; r < TK_HREP; ++r) acc += ld_u32(&row[r][t]);
+        for (int r = 0; r < TK_HREP; ++r) acc += plain ? row[r][t] : ld_u32(&row[r][t]);      // plain: written by an earlier launch
         suf[t] = acc;
     }
     {   // suffix sums S[t] = sum_{b >= t} hist[b]: within each wave by shuffles, then the totals of the waves above
