@@ -253,3 +253,56 @@ class ShardedSelector(object):
         mine, lam, coef, rhs, ks = ops.rows_of(ids)
         return dict(ids=ids, scores=res["scores"].cpu().numpy(), mine=mine, lam=lam, coef=coef, rhs=rhs, ks=ks,
                     new_strat=res["new_strat"], n_total=res["n_total"], counters=res["counters"])
+
+
+class ShardedQCQPRound(object):
+    """The QCQP composition of a round (cut_select_qcqp.py:63-103) over candidate shards.
+
+    Both covers of the instance are sharded lists, one :class:`ShardedSelector` (one library handle
+    per rank) each: the cover of the objective's sparsity pattern is ranked with ``strat``
+    (``:64-73``), the constraints-only cover with feasibility (``:75-77``), and the round takes
+    ``(A + B)[0:sel_size]`` (``:79``).  Every rank holds the replicated head and generates the rows
+    of the candidates it owns; the cut counts of ``:85-97`` are summed over the ranks.
+    BASELINE.json configs[4] (q_50_*, 5-variable sub-problems, the constraints-only cover of
+    1.4e6 candidates spread over the GPUs)."""
+
+    def __init__(self, sel_obj, sel_cons):
+        self.sel_obj, self.sel_cons = sel_obj, sel_cons
+
+    def round(self, strat, sel_size, vars_values):
+        """-> dict(new_strat, is_obj bool[w], ids int64[w] (global position in the cover the entry
+        comes from), scores fp64[w], nb_sdp_cuts, nb_opt_cuts, nb_cuts_combined,
+        rows_obj / rows_cons: dict(mine, lam, coef, rhs, ks) of this rank's own entries)"""
+        if strat not in (1, 2, 4):
+            raise ValueError("strategy must be 1, 2 or 4")
+        so, sc = self.sel_obj, self.sel_cons
+        new_strat, n_obj, nb_opt = strat, 0, 0
+        a = b = None
+        if so is not None and so.n_global > 0:
+            so.ops.scorer.set_point(vars_values)
+            a = so.select_round(strat, sel_size)
+            # detach: the views belong to the handle's pinned block and the next call reuses it
+            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.items()}
+            n_obj = len(a["ids"])                        # min(len(comb_obj), sel_size), :79
+            new_strat = a["new_strat"]
+            if strat != 1:
+                nb_opt = int(np.count_nonzero(a["scores"] > _BIG_M))       # :85-88 (entries beyond the head carry no +BIG_M)
+        rest = sel_size - n_obj
+        if rest > 0 and sc is not None and sc.n_global > 0:
+            sc.ops.scorer.set_point(vars_values)
+            b = sc.select_round(1, rest)
+        ids = np.concatenate([a["ids"] if a else np.empty(0, np.int64), b["ids"] if b else np.empty(0, np.int64)])
+        scores = np.concatenate([a["scores"] if a else np.empty(0), b["scores"] if b else np.empty(0)])
+        is_obj = np.zeros(ids.shape[0], dtype=bool)
+        # :90-92 counts the entries whose first field is an int -- the optimality / combined rankings' entries;
+        # under strategy 1 both parts are feasibility entries (index sets)
+        is_obj[:n_obj] = strat != 1
+        # cuts: an entry produces one unless its lambda_min >= -1e-15 (:737-739); own rows only, summed
+        own = 0
+        for part in (a, b):
+            if part is not None and len(part["lam"]):
+                own += int(np.count_nonzero(part["lam"] < -1e-15))
+        nb_cuts = (so or sc)._sum(own)
+        rows = lambda p: None if p is None else {k: p[k] for k in ("mine", "lam", "coef", "rhs", "ks")}
+        return dict(new_strat=new_strat, is_obj=is_obj, ids=ids, scores=scores, nb_sdp_cuts=nb_cuts, nb_opt_cuts=nb_opt,
+                    nb_cuts_combined=int(is_obj.sum()), rows_obj=rows(a), rows_cons=rows(b))

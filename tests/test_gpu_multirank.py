@@ -155,3 +155,82 @@ def test_two_ranks_one_gpu_sharded_selection(oracle, tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
+
+
+_QCQP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from sdpcutsel_via_nn_amd import _capi, harness, networks
+from sdpcutsel_via_nn_amd.distributed import DeviceOps, ShardedSelector, ShardedQCQPRound
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+G = os.path.join(%(root)r, "tests", "golden")
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+g = np.load(os.path.join(G, "inst_qcqp50.npz"))
+inst = harness.parse_osil(os.path.join(G, "instances", "q_50_10_25_1.osil"))
+n = inst["nb_vars"]
+(So, ko), (Sc, kc) = harness.qcqp_covers(inst, 5, _capi.enumerate_cover)
+
+
+def shard(S, k):
+    m = len(k)
+    lo, hi = rank * m // world, (rank + 1) * m // world
+    sc = _capi.Scorer(0)
+    for kk in range(2, 6):
+        sc.set_network(kk, *networks.load_network(kk))
+    sc.set_instance(n, inst["Q_arr"])
+    sc.set_candidates(S[lo:hi], k[lo:hi], global_base=lo)
+    return ShardedSelector(DeviceOps(sc, dev), hi - lo)
+
+
+rnd = ShardedQCQPRound(shard(So, ko), shard(Sc, kc))
+assert rnd.sel_obj.n_global == 4 and rnd.sel_cons.n_global == 1377077
+for strat in (4, 2, 1):
+    q = "s%%d" %% strat
+    r = rnd.round(strat, 5000, g["vars"])
+    assert r["new_strat"] == int(g[q + "_new_strat"]), (strat, r["new_strat"])
+    assert np.array_equal(r["is_obj"], g[q + "_is_obj"]), strat
+    ref_score, ref_ids = g[q + "_score"], g[q + "_ids"]
+    assert np.abs(r["scores"] - ref_score).max() <= 1e-9 * max(1.0, np.abs(ref_score).max()), strat
+    same = r["ids"] == ref_ids
+    bad = np.flatnonzero(~same)
+    for b in bad:       # the only admissible difference: neighbours whose reference scores agree to 1e-12 (LAPACK noise)
+        lo_, hi_ = max(b - 3, 0), min(b + 4, len(ref_ids))
+        assert np.ptp(ref_score[lo_:hi_][np.isin(ref_ids[lo_:hi_], r["ids"][lo_:hi_])]) <= 1e-12 * max(1.0, abs(ref_score[b])), (strat, b)
+    assert len(bad) <= 10
+    assert r["nb_opt_cuts"] == int(g[q + "_nb_opt_cuts"]) and r["nb_cuts_combined"] == int(g[q + "_is_obj"].sum())
+    # every rank generated the rows of exactly its own entries, and together they cover the head
+    n_obj = int(np.count_nonzero(r["is_obj"])) if strat != 1 else (len(r["rows_obj"]["mine"]) if r["rows_obj"] else 0)
+    own = sum(int(p["mine"].sum()) for p in (r["rows_obj"], r["rows_cons"]) if p is not None)
+    tot = torch.tensor([own]); dist.all_reduce(tot)
+    assert int(tot) == len(r["ids"]) == 5000, (strat, int(tot))
+    rc = r["rows_cons"]
+    lo_c = rnd.sel_cons.ops.scorer.base
+    mine_ids = r["ids"][n_obj:][rc["mine"]]
+    assert ((mine_ids >= lo_c) & (mine_ids < lo_c + rnd.sel_cons.n_local)).all()
+    lam, coef, rhs, _, ks = rnd.sel_cons.ops.scorer.cut_rows(mine_ids - lo_c)
+    assert np.array_equal(rc["lam"], lam) and np.array_equal(rc["coef"], coef[:, :rc["coef"].shape[1]]) and np.array_equal(rc["rhs"], rhs)
+    assert (rc["ks"] == 5).all() and r["nb_sdp_cuts"] > 0
+for s in (rnd.sel_obj, rnd.sel_cons):
+    s.ops.scorer.close()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_ranks_one_gpu_qcqp_round_at_full_size(tmp_path):
+    """BASELINE.json configs[4] over shards: q_50_10_25_1, 5-variable sub-problems, both covers split over two
+    ranks that share the test box's GPU (gloo); the composed head (cut_select_qcqp.py:79) against the round
+    the reference itself ran (tests/golden/inst_qcqp50.npz), rows against sdpcut_cut_rows."""
+    script = tmp_path / "qcqp_worker.py"
+    script.write_text(_QCQP_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29647", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
