@@ -138,13 +138,17 @@ import torch
 import torch.distributed as dist
 sys.path.insert(0, %(root)r)
 from sdpcutsel_via_nn_amd import _capi
-from sdpcutsel_via_nn_amd.distributed import ShardedSelector, _PAD_ID
+from sdpcutsel_via_nn_amd.distributed import ShardedSelector, ShardedQCQPRound, _PAD_ID
 from oracle import cutsel_oracle as oracle
 
 class FakeOps(object):
     """Stand-in for the two device calls (ranking of the local shard, merge), backed by the CPU
     oracle, so that the collective choreography can be rehearsed with gloo on a box without GPUs."""
     device = torch.device("cpu")
+    class _NoScorer(object):
+        def set_point(self, vv):
+            pass
+    scorer = _NoScorer()
     def __init__(self, obj, lam, base):
         self.obj, self.lam, self.base = obj, lam, base
     def local_head(self, strat, sel_size, count, want_secondary=False):
@@ -228,6 +232,27 @@ def main():
             assert np.array_equal(q["lam"], lam[order[:k][own]]) and q["ks"].shape[0] == int(own.sum())
             if strat == 4:
                 assert q["counters"]["strong"] == cnt["strong"] and q["counters"]["violated"] == cnt["violated"]
+    # QCQP composition over shards (cut_select_qcqp.py:79): objective cover ranked with the strategy, constraints-only
+    # cover with feasibility, head = (A + B)[0:sel]
+    for case, (na, nb, sel) in enumerate([(3, 900, 100), (40, 300, 25), (0, 500, 60), (16, 0, 10)]):
+        Na, Nb = na * world, nb * world
+        oa, la = np.abs(np.round(rng.normal(size=Na), 1)) + 0.1, np.round(rng.normal(size=Na) * 0.3, 2) - 0.001
+        ob, lb = np.round(rng.normal(size=Nb), 1), np.round(rng.normal(size=Nb) * 0.3, 2) - 0.001
+        sa = ShardedSelector(FakeOps(oa[rank * na:(rank + 1) * na], la[rank * na:(rank + 1) * na], rank * na), na)
+        sb = ShardedSelector(FakeOps(ob[rank * nb:(rank + 1) * nb], lb[rank * nb:(rank + 1) * nb], rank * nb), nb)
+        rnd = ShardedQCQPRound(sa, sb)
+        for strat in (1, 2, 4):
+            r = rnd.round(strat, sel, None)
+            order_a, score_a, new_strat, _ = oracle.rank_arrays(strat, oa, la, sel) if Na else (np.empty(0, np.int64), np.empty(0), strat, None)
+            n_obj = min(sel, order_a.shape[0])
+            order_b, score_b, _, _ = oracle.rank_arrays(1, ob, lb, sel) if Nb else (np.empty(0, np.int64), np.empty(0), 1, None)
+            n_b = min(sel - n_obj, order_b.shape[0])
+            assert np.array_equal(r["ids"], np.concatenate([order_a[:n_obj], order_b[:n_b]])), (case, strat, rank)
+            assert np.array_equal(r["scores"], np.concatenate([score_a[:n_obj], score_b[:n_b]]) + 0.0), (case, strat)
+            assert r["new_strat"] == new_strat and r["nb_cuts_combined"] == (n_obj if strat != 1 else 0)
+            assert r["nb_opt_cuts"] == (int((score_a[:n_obj] > 1000.0).sum()) if strat != 1 else 0)
+            lam_sel = np.concatenate([la[order_a[:n_obj]], lb[order_b[:n_b]]])
+            assert r["nb_sdp_cuts"] == int((lam_sel < -1e-15).sum()), (case, strat)
     dist.destroy_process_group()
     print("rank", rank, "ok")
 
