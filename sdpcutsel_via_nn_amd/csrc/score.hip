@@ -1126,16 +1126,20 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
     double *o_rhs = o_lam + cap;
     double *o_coef = o_rhs + cap;
     int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
+    const int64_t first = (int64_t)blockIdx.x * 64;
+    const int64_t i = first + lane;
+    // (requested before the head's length is known: one dependent trip to memory less on the critical path of a
+    // kernel that is a chain of them; an entry beyond the head is never dereferenced)
+    const int64_t gid_any = i < cap ? idx[i] : 0;
+    const double score_any = i < cap ? score[i] : 0.0;
     int64_t limit = cap;
     if (d_c4) {
         if (blockIdx.x == 0 && lane < 7) o_c4[lane] = d_c4[lane];     // counters, strong count, mode (TopkWs::counters)
         limit = d_c4[3];
         if (limit > cap) limit = cap;
     }
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int64_t i = first + lane;
     if (i < limit) {
-        const int64_t gid = idx[i];
+        const int64_t gid = gid_any;
         const int64_t c = gid - idx_base;
         double co[SDPCUT_ROW_LD];
         int64_t cl[SDPCUT_ROW_LD];
@@ -1143,6 +1147,10 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
         for (int m = 0; m < SDPCUT_ROW_LD; ++m) co[m] = 0.0;
         double lam = __builtin_nan(""), rhs = 0.0;
         int k = 0;
+        // ids and scores go out first: the kernel ends in a burst of 0.54 MB over PCIe (~8 us at the link's rate, most of
+        // what the kernel takes beyond its launch) -- what is known before the eigenvectors travels while they are computed
+        o_idx[i] = gid;
+        o_score[i] = score_any;
         if (c >= 0 && c < n_local) {
             k = ks[c];
             const int32_t *s5 = set5 + c * 5;
@@ -1153,8 +1161,6 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
             default: cut_row_one<5>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
             }
         }
-        o_idx[i] = gid;
-        o_score[i] = score[i];
         o_lam[i] = lam;
         o_rhs[i] = rhs;
         o_ks[i] = k;
