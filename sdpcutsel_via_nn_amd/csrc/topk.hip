@@ -1,4 +1,4 @@
-// Top-k selection on the device (k <= 8192) -- the fast path of the ranking.
+// Top-k selection on the device (k <= 16384) -- the fast path of the ranking.
 //
 // The reference sorts all N candidates (cut_select_qp.py:601, :653) but its caller consumes
 // only the first sel_size <= 5000 (_SDP_CUTS_PER_ROUND_MAX, :37).  For such heads a full sort
@@ -18,6 +18,11 @@
 // the release/acquire.  Histogram cells and counters are written with device-scope atomics
 // and read back by the resolving block with device-scope atomic loads (per-XCD L2s are not
 // coherent for plain loads inside a launch).
+//
+// A round that scores for itself (sdpcut_select_round on a fresh point) does not run the first pass
+// here: the score kernels count the leading digit of the class members' keys (score.hip, ScoreArgs::tk)
+// and tk_refine_kernel<true> starts at the second digit, building the keys from the scores as it
+// reads them -- tk_keys_kernel and the key array are for selections over scores that exist already.
 
 #include "topk_dev.h"
 
@@ -1024,21 +1029,21 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
         rc = topk_begin(h, nullptr, nullptr);
         if (rc) return rc;
     }
-    const bool keys_done = stage == 3;
+    const bool digit_done = stage == 3;      // the score kernels counted digit 0; no key array (tk_refine_kernel<true>)
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
     const double *eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const double *obj = (h->scored & SDPCUT_NN) ? h->d_obj : nullptr;
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    const bool small = !keys_done && n <= maxk;
+    const bool small = !digit_done && n <= maxk;
     if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
-    } else if (!keys_done) {
+    } else if (!digit_done) {
         hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
     }
-    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base, TK_MAXK, keys_done, sel,
+    rc = topk_enqueue_after_pass0(h, ws, mode, n, k, score_add, d_idx_out, d_score_out, small, 0, h->base, TK_MAXK, digit_done, sel,
                                   eig, obj);
     if (rc) return rc;
     if (d_counters_out) *d_counters_out = ws->counters;
