@@ -273,7 +273,7 @@ def main():
                 sc.set_point(vv_host)
                 # score the shard + packed head record (one call) -> ONE all-gather (RCCL) -> replicated merge ->
                 # each rank generates the rows of its own candidates -> one D2H, one host sync
-                res = sel.select_round(4, SEL)
+                res = sel.select_round(4, SEL, copy=False)
             if timed:
                 kernel_ms.append(sc.last_timing()[0])
                 sc.set_option(_capi.OPT_TIMING, 0)

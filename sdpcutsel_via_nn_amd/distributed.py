@@ -200,7 +200,7 @@ class ShardedSelector(object):
         return dict(ids=ids, scores=scores, new_strat=new_strat, n_total=self.n_global,
                     counters=dict(strong=strong, violated=violated))
 
-    def select_round(self, strat, sel_size):
+    def select_round(self, strat, sel_size, copy=True):
         """Selection AND eigen-cut rows of one round (cut_select_qp.py:165-182) over all shards
         -> dict(ids, scores, mine, lam, coef, rhs, ks, new_strat, n_total, counters), numpy.
 
@@ -215,6 +215,9 @@ class ShardedSelector(object):
         its counters are packed on the device, all-gathered, merged and turned into rows by
         two library calls (shard_head / shard_finish).  Otherwise :meth:`select` runs.
 
+        copy=False: ``ids`` / ``scores`` are views of that block as well (no host copies at all on the round's
+        critical path; the +BIG_M of the combined strategy is added in place).
+
         The shard need not be scored beforehand: shard_head scores what the current point lacks (and,
         when nothing has been scored yet, lets the score kernels prepare the selection's first radix
         digit); :meth:`select` on its own expects the scores (``ops.ensure_scored``)."""
@@ -226,7 +229,8 @@ class ShardedSelector(object):
             rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel)
             own = hasattr(ops, "shard_finish_own")
             out = (ops.shard_finish_own if own else ops.shard_finish)(self.world, sel, self._all_gather(rec), sel)
-            g = out["headers"].sum(axis=0)
+            hdr = out["headers"]
+            g = (hdr[0] if hdr.shape[0] == 1 else hdr.sum(axis=0)).tolist()
             length = int(g[0])
             # g[4] != 0: some shard's selection gave up (csrc/topk.hip), its record is void
             if int(g[4]) == 0 and (strat != 4 or length >= sel):
@@ -234,8 +238,13 @@ class ShardedSelector(object):
                 cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))
                 if strat == 4:
                     cnt.update(strong=sel, violated=sel)
-                res = dict(ids=out["idx"][:valid].copy(), scores=out["score"][:valid] + (_BIG_M if strat == 4 else 0.0),
-                           new_strat=strat, n_total=self.n_global if strat != 1 else length, counters=cnt)
+                if copy or not own:
+                    ids, scores = out["idx"][:valid].copy(), out["score"][:valid] + (_BIG_M if strat == 4 else 0.0)
+                else:
+                    ids, scores = out["idx"][:valid], out["score"][:valid]
+                    if strat == 4:
+                        scores += _BIG_M
+                res = dict(ids=ids, scores=scores, new_strat=strat, n_total=self.n_global if strat != 1 else length, counters=cnt)
                 if own:      # rows compacted by the library: views of its host block, valid until the next round
                     w = out["n_own"]
                     mine = np.zeros(valid, dtype=bool)
