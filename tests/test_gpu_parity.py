@@ -743,6 +743,14 @@ def test_select_round_equals_separate_calls(full_c2, scorer, strat):
     assert np.array_equal(v["lam"], lam) and np.array_equal(v["coef"], coef[:, :9]) and np.array_equal(v["rhs"], rhs)
     with pytest.raises(ValueError):
         scorer.select_round(strat, 5000, point=wl["vars_values"][:-1])
+    # what the current point has scores for (SDPCUT_STAT_SCORED): a fresh point nothing, a round what its strategy ranks by
+    need = {1: _capi.EIG, 2: _capi.NN, 4: _capi.EIG | _capi.NN}[strat]
+    scorer.set_point(wl["vars_values"])
+    assert scorer.get_stat(_capi.STAT_SCORED) == 0
+    scorer.select_round(strat, 33)
+    assert scorer.get_stat(_capi.STAT_SCORED) == need
+    scorer.score(_capi.EIG | _capi.NN)
+    assert scorer.get_stat(_capi.STAT_SCORED) == (_capi.EIG | _capi.NN)
     # without the leading-digit histograms from the score kernels (the selection runs its own key pass): same results
     scorer.set_option(_capi.OPT_FUSE_KEYS, 0)
     try:

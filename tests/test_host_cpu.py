@@ -39,6 +39,15 @@ def test_header_constants_match_binding():
     assert (vals["SDPCUT_STRAT_FEAS"], vals["SDPCUT_STRAT_OPT"], vals["SDPCUT_STRAT_COMB"]) == (1, 2, 4)
     assert vals["SDPCUT_PART_STRONG"] == _capi.PART_STRONG
     assert int(re.search(r"#define SDPCUT_ROW_LD (\d+)", hdr).group(1)) == _capi.ROW_LD
+    # (option / statistic codes: from the enum bodies only -- the comments around them quote values too)
+    enums = " ".join(re.findall(r"enum\s*\{([^}]*)\}", hdr))
+    vals = dict((k, int(v)) for k, v in re.findall(r"(SDPCUT_\w+)\s*=\s*(-?\d+)", enums))
+    for name in ("KERNEL", "TIMING", "FUSE_KEYS", "AUTO_REGIME", "FUSED_TAIL", "COOP_LAUNCH"):
+        assert vals["SDPCUT_OPT_" + name] == getattr(_capi, "OPT_" + name), name
+    for name in ("ROUNDS", "SELECT_FALLBACKS", "SCORED"):
+        assert vals["SDPCUT_STAT_" + name] == getattr(_capi, "STAT_" + name), name
+    assert (vals["SDPCUT_KERNEL_MFMA"], vals["SDPCUT_KERNEL_SIMPLE"], vals["SDPCUT_KERNEL_VALU"]) == (
+        _capi.KERNEL_MFMA, _capi.KERNEL_SIMPLE, _capi.KERNEL_VALU)
 
 
 def test_product_fails_loudly_without_gpu(built_lib):
