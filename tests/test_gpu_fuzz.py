@@ -164,3 +164,47 @@ def test_rounds_that_score_for_themselves_against_the_oracle(lib, oracle, seed):
                 assert voids[0] == voids[1], (seed, strat, sel, voids)
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_scores_over_hundreds_of_binades(lib, oracle, seed):
+    """Objective coefficients from 1e-120 to 1e+120 (both signs): obj_improve spreads over hundreds of binades, so
+    the leading radix digit the score kernel counts takes dozens of values inside one wave (its aggregation loop
+    runs out of rounds and falls back to per-lane adds) and the selection's threshold lands in arbitrary bins,
+    negative keys included.  Rounds that score for themselves against the oracle's ranking of the device's scores."""
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    rng = np.random.default_rng(7000 + seed)
+    n, N = 30, int(rng.choice([20000, 70001]))
+    L = n * (n + 1) // 2
+    Q = np.where(rng.uniform(size=L) < 0.5, -1.0, 1.0) * 10.0 ** rng.uniform(-120, 120, size=L)
+    ks = rng.choice([2, 3], size=N).astype(np.int32)
+    sets = np.full((N, 5), -1, dtype=np.int32)
+    for k in (2, 3):
+        m = ks == k
+        sets[m, :k] = synthetic.random_index_sets(n, k, int(m.sum()), rng)
+    vv = _point(rng, n, "gen")
+    sc = lib.Scorer(0)
+    try:
+        for k in (2, 3):
+            sc.set_network(k, *networks.load_network(k))
+        sc.set_instance(n, Q)
+        sc.set_candidates(sets, ks)
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.isfinite(obj).all()
+        expo = np.frexp(np.abs(obj[obj != 0]))[1]
+        assert expo.max() - expo.min() > 300           # the spread the test is about
+        for strat in (2, 4, 1):
+            for sel in (1, 500, 5000, 8192):
+                order, ref_score, ref_strat, ref_cnt = oracle.rank_arrays(strat, obj, eig, sel)
+                w = min(sel, order.shape[0])
+                for fuse in (1, 0):
+                    sc.set_option(_capi.OPT_FUSE_KEYS, fuse)
+                    sc.set_point(vv)
+                    r = sc.select_round(strat, sel)
+                    assert np.array_equal(r["idx"], order[:w]), (seed, strat, sel, fuse)
+                    assert np.array_equal(r["score"], ref_score[:w] + 0.0), (seed, strat, sel, fuse)
+                    assert r["new_strat"] == ref_strat and r["n_total"] == order.shape[0]
+    finally:
+        sc.close()
