@@ -916,3 +916,38 @@ def test_combined_all_visited_ties_by_obj_improve(full_c2, scorer, oracle, count
         scorer.set_candidates(wl["set_inds"], wl["ks"])
         scorer.set_point(wl["vars_values"])
         scorer.score(_capi.EIG | _capi.NN)
+
+
+def test_masses_of_equal_keys_beyond_the_lds_cache(lib, oracle):
+    """1.3e6 candidates at a structured point, rounds that score for themselves: a workgroup's chunk of the list
+    (5079 keys) no longer fits the selection's LDS cache, so every digit pass, the counts and the cut of the last
+    tie group by index rebuild their keys from the scores in memory -- through all eight digits (the eigenvalue
+    takes a handful of values shared by 1e4..1e6 candidates)."""
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    n, N = 100, 1300000
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=N, seed=5)
+    sc = lib.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        X = np.full((n, n), 0.1)
+        for v in range(3):
+            X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+        vv = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.unique(eig, return_counts=True)[1].max() > 8192 * 2
+        for strat in (1, 2, 4):
+            for sel in (5000, 8192, 77):
+                order, ref_score, ref_strat, _ = oracle.rank_arrays(strat, obj, eig, sel)
+                for fuse in (1, 0):
+                    sc.set_option(_capi.OPT_FUSE_KEYS, fuse)
+                    sc.set_point(vv)
+                    r = sc.select_round(strat, sel, copy=False)
+                    assert np.array_equal(r["idx"], order[:sel]), (strat, sel, fuse)
+                    assert np.array_equal(r["score"], ref_score[:sel] + 0.0), (strat, sel, fuse)
+                    assert r["new_strat"] == ref_strat
+    finally:
+        sc.close()
