@@ -17,6 +17,11 @@ the round's results are back in host memory when the step ends.
                 the device by the counter-based Philox generator (candidate id -> index set), rank r
                 takes ids [r, r+1) * 1e8 / N: strong scaling.
   c4-shard      one rank's share of the 8-GPU form of c4 (1.25e7 candidates per GPU).
+  c3            BASELINE.json configs[2] as real callers run it: the dim-4 cover of spar125-075-1 (1 700 215 mixed
+                2/3/4-variable sets, enumerated on the device) at two LP points the reference's own trajectory recorded
+                (tests/golden/rounds_spar125_075_1_d4_s4.npz: round 2 = combined strategy, round 8 = feasibility), through
+                the fused C-ABI calls AND through the drop-in pair _sel_eigcut_by_ordering_on_measure + _gen_eigcuts_selected
+                (cut_select_qp.py:165-182).  The default (c2) run carries the same numbers as secondary.c3.
 
 `value` = candidates scored per second over all ranks.  Rank 0 prints ONE JSON line.
 """
@@ -121,6 +126,119 @@ def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
     return out
 
 
+# ----------------------------------------------------------------------------- c3: the round as real callers run it
+C3_INSTANCE, C3_DIM, C3_ROUNDS = "spar125-075-1", 4, {4: 2, 1: 8}      # strategy -> recorded round whose LP point is replayed
+
+
+def c3_setup(device_index):
+    """-> (CutSolver bound to the device-enumerated cover, its Scorer, {strategy: LP point}, candidate count)"""
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolver, DeviceAgg
+    gold = os.path.join(ROOT, "tests", "golden")
+    inst = harness.parse_boxqp(os.path.join(gold, "instances", C3_INSTANCE + ".in"))
+    g = np.load(os.path.join(gold, "rounds_%s_d%d_s4.npz" % (C3_INSTANCE.replace("-", "_"), C3_DIM)))
+    pts = {}
+    for strat, r in C3_ROUNDS.items():
+        assert int(g["r%02d_strat" % r]) == strat
+        pts[strat] = np.ascontiguousarray(g["r%02d_vars" % r], dtype=np.float64)
+    cs = CutSolver(device_index)
+    cs._dim, cs._nb_vars, cs._nb_lifted, cs._Q_arr = C3_DIM, inst["nb_vars"], inst["nb_lifted"], inst["Q_arr"]
+    cs._load_neural_nets()
+    sc = cs._gpu_new_scorer()
+    sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+    n = sc.set_candidates_cover(inst["adj"], C3_DIM)
+    assert n == int(g["nb_subproblems"])
+    cs._agg_list = DeviceAgg(sc, n, inst["nb_vars"], inst["Q_arr"])
+    cs._my_prob = harness.LinearRelaxation(np.zeros(inst["nb_lifted"] + inst["nb_vars"]))
+    return cs, sc, pts, n
+
+
+def c3_steps(cs, sc):
+    """the three ways through one separation round: name -> f(strategy, LP point) -> number of cuts"""
+    from sdpcutsel_via_nn_amd import harness
+
+    def fused_rows(strat, vv):          # sdpcut_round_view: padded rows in the pinned block
+        return int((sc.select_round(strat, SEL, copy=False, point=vv)["lam"] < -1e-15).sum())
+
+    def fused_csr(strat, vv):           # sdpcut_round_csr: the cuts assembled on the device
+        return sc.round_csr(strat, SEL, point=vv)["rhs"].shape[0]
+
+    def dropin_pair(strat, vv):         # the reference's loop body, cut_select_qp.py:165-182, rows into a fresh row store
+        cs._my_prob.linear_constraints = harness._RowStore()
+        if strat == 4:
+            _, picked = cs._sel_eigcut_by_ordering_on_measure(strat, vv, 1, sel_size=SEL)
+        else:
+            picked = cs._sel_eigcut_by_ordering_on_measure(strat, vv, 1)
+        return cs._gen_eigcuts_selected(strat, SEL, picked, strong_only=False, vars_values=vv)
+
+    return {"fused_rows": fused_rows, "fused_csr": fused_csr, "dropin_pair": dropin_pair}
+
+
+def bench_c3(device_index, steps, warm=20):
+    """ms per separation round on the c3 cover: {"strategy_4": {...}, "strategy_1": {...}} + score-kernel times"""
+    import torch
+    from sdpcutsel_via_nn_amd import _capi
+    cs, sc, pts, n = c3_setup(device_index)
+    out = {"cover": "%s dim %d, %d candidates of 2..%d variables (device enumeration)" % (C3_INSTANCE, C3_DIM, n, C3_DIM),
+           "sel_size": SEL, "steps": steps,
+           "points": "LP points of rounds %s of the reference trajectory (tests/golden)" % sorted(C3_ROUNDS.values())}
+    fns = c3_steps(cs, sc)
+    for strat in (4, 1):
+        vv, res = pts[strat], {}
+        for name, f in fns.items():
+            for _ in range(warm):
+                cuts = f(strat, vv)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                f(strat, vv)
+            torch.cuda.synchronize()
+            res[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+            res["cuts"] = cuts
+        # score kernels of this strategy's round (event pair on the dispatches: first to last size class)
+        sc.set_option(_capi.OPT_TIMING, 1)
+        ms = []
+        for _ in range(10):
+            fns["fused_csr"](strat, vv)
+            ms.append(sc.last_timing()[0])
+        sc.set_option(_capi.OPT_TIMING, 0)
+        res["score_kernels_ms"] = float(np.mean(ms))
+        res["candidates_per_s_dropin"] = n / (res["dropin_pair_ms"] * 1e-3)
+        out["strategy_%d" % strat] = res
+    sc.close()
+    return out
+
+
+def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
+    """the feasibility round (strategy 1) on the main workload: eigenvalue-only kernel + selection + rows"""
+    import torch
+    from sdpcutsel_via_nn_amd import _capi
+    sc, _, _, _ = make_scorer(K, n_local, 7, 0)
+    for _ in range(30):
+        sc.select_round(1, SEL, copy=False, point=vv_host)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc.select_round(1, SEL, copy=False, point=vv_host)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sc.set_option(_capi.OPT_TIMING, 1)
+    ms = []
+    for _ in range(10):
+        sc.select_round(1, SEL, copy=False, point=vv_host)
+        ms.append(sc.last_timing()[0])
+    sc.close()
+    k_ms = float(np.mean(ms))
+    bytes_per = 4 * K + 8             # index set in, one fp64 out
+    gbs = bytes_per * n_local / (k_ms * 1e-3) / 1e9
+    return {"value": n_local / dt, "unit": "candidates/s", "ms_per_step": dt * 1e3, "steps": steps, "strategy": 1,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "eig_only_kernel<%d, true>" % K, "kernel_ms": k_ms,
+                         "candidates_per_launch": n_local, "bytes_per_candidate": bytes_per,
+                         "note": "gather + register Jacobi, no MLP: bound by VALU instruction issue (DESIGN.md section 5), "
+                                 "the HBM figure is the algorithmic one"}}
+
+
 class _StdoutToStderr(object):
     """fd-level redirect: native libraries (RCCL prints a version banner when its first communicator
     comes up) must not put lines on stdout, which carries exactly one JSON line."""
@@ -150,7 +268,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2")
+    ap.add_argument("--no-c3", action="store_true", help="skip secondary.c3 (the spar125-075-1 dim-4 rounds) of the default run")
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the k = 2, 4, 5 single-GPU rates")
@@ -168,6 +287,8 @@ def main():
     ap.add_argument("--time-every", type=int, default=8,
                     help="attach the HIP event pair to the score dispatch of every n-th step of the timed region")
     args = ap.parse_args()
+    if args.config == "c3":
+        return main_c3(args)
     cfg = CONFIGS[args.config]
 
     import torch
@@ -360,6 +481,10 @@ def main():
                                    "kernel_ms": r2["kernel_ms"], "roofline_frac": r2["frac"], "achieved_TFLOPs": r2["achieved"]}
                 s2.close()
             out["secondary"] = sec
+            # the feasibility round (strategy 1, cut_select_qp.py:639-654) on the same list: the eigenvalue-only kernel
+            out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
+            if not args.no_c3:
+                out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
         if world == 1 and not args.no_cpu_baseline:
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample
                 m = min(args.cpu_sample, n_local)
@@ -369,6 +494,37 @@ def main():
     sc.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def main_c3(args):
+    """--config c3: the spar125-075-1 dim-4 rounds as the line's workload (one GPU).  value = candidates per second
+    through the drop-in pair with the combined strategy (every candidate scored eig + NN, the round ranked and its
+    cuts handed to the LP's row store); the other routes and the feasibility point ride along in `c3`."""
+    import torch
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        sys.exit("--config c3 is a one-GPU workload (a real cover does not grow with the number of GPUs)")
+    torch.cuda.set_device(0)
+    import __graft_entry__ as entry
+    with _StdoutToStderr():
+        entry.build()
+    import gc
+    gc.collect()
+    gc.freeze()
+    res = bench_c3(0, args.steps, warm=max(args.warmup, 20))
+    n = int(res["cover"].split(",")[1].split()[0])
+    s4 = res["strategy_4"]
+    flops = 11500.0        # per candidate of the dominant class (4-variable sets); the event pair spans all three size classes
+    tflops = flops * n / (s4["score_kernels_ms"] * 1e-3) / 1e12
+    out = {"metric": BASELINE_METRIC, "value": n / (s4["dropin_pair_ms"] * 1e-3), "unit": "candidates/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": s4["dropin_pair_ms"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "instance file + recorded LP points (tests/golden)",
+           "config": {"workload": "configs[2]: " + res["cover"] + ", combined strategy, sel_size 5000, through the drop-in pair "
+                                  "_sel_eigcut_by_ordering_on_measure + _gen_eigcuts_selected", "config": "c3"},
+           "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+                        "traffic": None, "kernel": "score_mfma_kernel<2|3|4, ...> (three size classes, first start to last end)",
+                        "kernel_ms": s4["score_kernels_ms"], "candidates_per_launch": n, "flops_per_candidate": flops},
+           "c3": res}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -72,8 +72,11 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * threads, 38 KB of LDS each), which an otherwise idle device always holds, and every wait is bounded: a
  * barrier that does not complete within a few milliseconds voids the selection and the full-sort path
  * answers (counted by SDPCUT_STAT_SELECT_FALLBACKS). */
+/* SDPCUT_OPT_EIG_KERNEL (default 1): launches that compute only lambda_min (feasibility rounds,
+ * cut_select_qp.py:639-654) run the dedicated eigenvalue kernel -- one launch over all size classes, compiled
+ * without the MLP's register state -- instead of the scoring kernels' eigenvalue branch (0: A/B). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
-       SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6 };
+       SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6, SDPCUT_OPT_EIG_KERNEL = 7 };
 
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier
@@ -265,6 +268,43 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
 int sdpcut_round_view(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, int32_t coef_ld,
                       const void **block, int64_t *cap_out, int64_t *n_out,
                       int64_t *n_total, int32_t *new_strat, int64_t *counters);
+
+/*
+ * One cutting-plane round with the cuts ASSEMBLED: everything the separation step of cut_select_qp.py:165-182 hands
+ * to the LP -- _sel_eigcut_by_ordering_on_measure (:543-703), _gen_eigcuts_selected (:705-755) and the row objects
+ * the latter builds one cut at a time (cplex.SparsePair(ind=[L + i for i in set_inds] + Xarr_inds, val=coeffs),
+ * rhs -v0^2, sense "G"; :744-750) -- as one block of rows in compressed sparse row form, assembled on the device
+ * and stored straight into a pinned host block owned by the handle (SURVEY.md section 8 f row 4).
+ *
+ * vars_values: the LP point [X packed | x] (sdpcut_set_point is part of the call), or NULL to keep the current one.
+ * sel_size: the strategy's quota AND the number of head entries returned (cap = min(sel_size, N)).
+ * All pointers of *out point INTO the handle's block: valid until the next call on the handle, never freed by the caller.
+ *   head (n_out entries, rank order):  idx (global candidate ids), score, lam_min (NaN for a candidate of another
+ *       shard), ks (candidate size), set_inds [.][5] (index sets padded with -1)
+ *   cuts (n_rows <= n_out; an entry yields one iff its lam_min < -1e-15, :739), in head order:
+ *       row_entry[r] = head position of cut r;  rhs[r];  indptr[r] .. indptr[r + 1] = its span in indices / values
+ *       (n_rows + 1 entries, indptr[n_rows] = nnz);  indices = LP columns (:747),  values = coefficients (:745-746).
+ * The cuts of the first m head entries are rows 0 .. r-1 with r = #{row_entry < m} (row_entry ascends), i.e. a
+ * prefix of the block: a caller that consumes fewer entries (strong_only, :725-726) slices, nothing is recomputed.
+ */
+typedef struct sdpcut_round_csr {
+    int64_t cap, n_out, n_total;
+    int32_t new_strat;
+    int32_t row_ld;                 /* longest possible row (k + k(k+1)/2 of the largest candidate size): indices / values hold cap * row_ld */
+    int64_t counters[4];            /* as sdpcut_rank */
+    const int64_t *idx;
+    const double *score;
+    const double *lam_min;
+    const int32_t *ks;
+    const int32_t *set_inds;
+    int64_t n_rows, nnz;
+    const int32_t *row_entry;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const double *values;
+    const double *rhs;
+} sdpcut_round_csr_t;
+int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, sdpcut_round_csr_t *out);
 
 /*
  * The same round over candidate shards (one handle per GPU, SURVEY 8 e): the two device-side

@@ -16,7 +16,7 @@ EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
 PART_STRONG = 104
 KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
-OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL, OPT_COOP_LAUNCH = 1, 2, 3, 4, 5, 6
+OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL, OPT_COOP_LAUNCH, OPT_EIG_KERNEL = 1, 2, 3, 4, 5, 6, 7
 STAT_ROUNDS, STAT_SELECT_FALLBACKS, STAT_SCORED = 1, 2, 3
 ROW_LD = 20
 
@@ -25,6 +25,14 @@ _i32p = _c.POINTER(_c.c_int32)
 _i64p = _c.POINTER(_c.c_int64)
 _dp = _c.POINTER(_c.c_double)
 _vp = _c.c_void_p
+
+class RoundCsr(_c.Structure):
+    """sdpcut_round_csr_t of include/sdpcut.h"""
+    _fields_ = [("cap", _c.c_int64), ("n_out", _c.c_int64), ("n_total", _c.c_int64), ("new_strat", _c.c_int32), ("row_ld", _c.c_int32),
+                ("counters", _c.c_int64 * 4), ("idx", _vp), ("score", _vp), ("lam_min", _vp), ("ks", _vp), ("set_inds", _vp),
+                ("n_rows", _c.c_int64), ("nnz", _c.c_int64), ("row_entry", _vp), ("indptr", _vp), ("indices", _vp),
+                ("values", _vp), ("rhs", _vp)]
+
 
 # name -> argtypes (restype is c_int unless listed in _RESTYPES); kept in one table so that the
 # CPU test-suite can check that the library exports every symbol the header declares
@@ -57,6 +65,7 @@ SIGNATURES = {
     "sdpcut_select_round": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _i64p, _dp, _dp, _dp, _dp, _i32p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_select_round_view": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_round_view": [_vp, _dp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
+    "sdpcut_round_csr": [_vp, _dp, _c.c_int, _c.c_int64, _c.POINTER(RoundCsr)],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
@@ -152,6 +161,7 @@ class Scorer(object):
         self.N = 0
         self.nb_vars = 0
         self.base = 0
+        self.round_count = 0     # rounds that wrote the handle's pinned host block (views of it are good until the next one)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -332,6 +342,7 @@ class Scorer(object):
         (sdpcut_select_round_view).  copy=False returns numpy views of that block: no host copy
         at all, valid until the next call on this Scorer; copy=True (default) detaches them."""
         ld = self.row_len
+        self.round_count += 1
         block, cap, n_out, n_total, new_strat = _c.c_void_p(), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
         cnt = np.zeros(4, dtype=np.int64)
         if point is not None:
@@ -371,6 +382,55 @@ class Scorer(object):
                     counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]),
                                   nb_positive=int(cnt[3])))
 
+    def round_csr(self, strat, sel_size, point=None, copy=False):
+        """One round with the cuts assembled on the device (sdpcut_round_csr): LP point -> score -> rank -> eigen-cuts
+        of the head as ONE CSR block -> dict(idx, score, lam, ks, set_inds [., 5], n_total, new_strat, counters,
+        row_entry, indptr, indices, values, rhs).  The arrays are numpy views of the handle's pinned host block (written
+        by the device, valid until the next call on this Scorer); copy=True detaches them.  point=None keeps the
+        current LP point."""
+        vv = None
+        if point is not None:
+            vv = _f64(point)
+            n = self.nb_vars
+            if vv.shape != (n * (n + 1) // 2 + n,):
+                raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
+        self.round_count += 1
+        out = getattr(self, "_csr_struct", None)
+        if out is None:
+            out = self._csr_struct = RoundCsr()
+        self._check(self._lib.sdpcut_round_csr(self._h, _ptr(vv, _dp), int(strat), int(sel_size), ctypes.byref(out)))
+        c, w, r = int(out.cap), int(out.n_out), int(out.n_rows)
+        if c and out.idx:
+            key = (out.idx, c, int(out.row_ld))
+            if getattr(self, "_csr_view_key", None) != key:       # the block is reused round after round
+                ld = int(out.row_ld)
+
+                def view(ptr, dtype, count, shape=None):
+                    a = np.frombuffer((_c.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype, count=count)
+                    return a.reshape(shape) if shape else a
+                self._csr_views = dict(
+                    idx=view(out.idx, np.int64, c), score=view(out.score, np.float64, c), lam=view(out.lam_min, np.float64, c),
+                    ks=view(out.ks, np.int32, c), set_inds=view(out.set_inds, np.int32, 5 * c, (c, 5)),
+                    row_entry=view(out.row_entry, np.int32, c), indptr=view(out.indptr, np.int32, c + 1),
+                    indices=view(out.indices, np.int32, c * ld), values=view(out.values, np.float64, c * ld),
+                    rhs=view(out.rhs, np.float64, c))
+                self._csr_view_key = key
+            v = self._csr_views
+            nnz = int(out.nnz)
+            res = dict(idx=v["idx"][:w], score=v["score"][:w], lam=v["lam"][:w], ks=v["ks"][:w], set_inds=v["set_inds"][:w],
+                       row_entry=v["row_entry"][:r], indptr=v["indptr"][:r + 1], indices=v["indices"][:nnz],
+                       values=v["values"][:nnz], rhs=v["rhs"][:r])
+            if copy:
+                res = {k: a.copy() for k, a in res.items()}
+        else:
+            z = np.zeros
+            res = dict(idx=z(0, np.int64), score=z(0), lam=z(0), ks=z(0, np.int32), set_inds=z((0, 5), np.int32),
+                       row_entry=z(0, np.int32), indptr=z(1, np.int32), indices=z(0, np.int32), values=z(0), rhs=z(0))
+        cnt = out.counters
+        res.update(n_total=int(out.n_total), new_strat=int(out.new_strat),
+                   counters=dict(nb_violated=int(cnt[0]), strong=int(cnt[1]), violated=int(cnt[2]), nb_positive=int(cnt[3])))
+        return res
+
     # ------------------------------------------------------------------ sharded round (multi-GPU)
     def shard_head_device(self, strat, count, d_record_ptr):
         """enqueue this shard's packed head record (8 + 2*count int64 words); no host sync"""
@@ -400,6 +460,7 @@ class Scorer(object):
         numpy views of the handle's pinned host block, which the device wrote directly
         (valid until the next call on this Scorer; copy=True detaches them)"""
         m, ld, w = int(sel_size), self.row_len, int(world)
+        self.round_count += 1
         block = _c.c_void_p()
         self._check(self._lib.sdpcut_shard_finish_round_view(
             self._h, w, int(count), _vp(d_allrec_ptr), m, ld, ctypes.byref(block)))
@@ -411,6 +472,7 @@ class Scorer(object):
         (compacted in head order by the library) and pos[:n_own] their positions in the head
         -> dict(headers, idx, score, lam, coef, rhs, ks, pos, n_own); views, see above"""
         m, ld, w = int(sel_size), self.row_len, int(world)
+        self.round_count += 1
         block, n_own = _c.c_void_p(), _c.c_int64(0)
         self._check(self._lib.sdpcut_shard_finish_round_own(
             self._h, w, int(count), _vp(d_allrec_ptr), m, ld, ctypes.byref(block), ctypes.byref(n_own)))

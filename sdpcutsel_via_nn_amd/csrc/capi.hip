@@ -236,6 +236,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_AUTO_REGIME:
         h->auto_regime = value != 0;
         return SDPCUT_OK;
+    case SDPCUT_OPT_EIG_KERNEL:
+        h->eig_kernel = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
@@ -501,7 +504,6 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
     if (h->point_stage_bytes < bytes) {
         HIP_TRY(h, sdpcut_sync(h));
         if (h->point_stage) (void)hipHostFree(h->point_stage);
-    (void)hipFree(h->d_done_ticket);
         h->point_stage = nullptr;
         h->point_stage_bytes = 0;
         HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocMapped));
@@ -695,10 +697,13 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
     return SDPCUT_OK;
 }
 
-int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, const void **block,
-                             int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
+} // extern "C"
+
+// One fused round: score (if needed) -> rank -> epilogue.  csr = false: padded rows, block layout of
+// sdpcut_select_round_view; csr = true: the CSR block of sdpcut_round_csr (rows.hip, csr_layout).
+static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_ld, bool csr, const void **block,
+                      int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
 {
-    if (!h) return SDPCUT_EINVAL;
     if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_STRAT_COMB)
         return sdpcut_fail(h, SDPCUT_EINVAL, "strategy must be 1 (feasibility), 2 (optimality) or 4 (combined)");
     if (sel_size < 0 || !block || !cap_out || !n_out) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
@@ -721,8 +726,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         return sdpcut_rank(h, strat, sel_size, 0, nullptr, nullptr, n_total, new_strat, counters);
     // one block for everything a round returns: counters | idx | score | lam | rhs | coef | ks
     const size_t c = (size_t)cap;
-    const size_t ret_bytes = 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4;
-    rc = ensure_stage(h, ret_bytes + 64);
+    const size_t ret_bytes = csr ? csr_layout(cap, coef_ld).bytes : 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4;
+    rc = ensure_stage(h, 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4 + 64);
     if (rc) return rc;
     rc = ensure_pinned(h, ret_bytes);
     if (rc) return rc;
@@ -737,6 +742,8 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
     if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
     int64_t w = 0;
     bool have = false;
+    int64_t *hdr = (int64_t *)h->pinned;
+    if (csr) hdr[8] = hdr[9] = hdr[10] = 0;
     // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
     // results directly into the pinned host block (no copy engine); one synchronisation
     const int64_t *d_cnt = nullptr;
@@ -747,13 +754,14 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
         // the epilogue's last workgroup publishes this round's serial number in the block's header: the
         // host polls that word instead of waiting for the runtime's completion signal (~5 us earlier)
-        int64_t *hdr = (int64_t *)h->pinned;
         const int64_t serial = ++h->round_serial;
-        rc = launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
+        rc = csr ? launch_round_csr(h, cap, d_cnt, cap, d_idx, d_sc, coef_ld, h->pinned_dev, serial)
+                 : launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
         if (rc) return rc;
         rc = wait_round_done(h, hdr + 7, serial);
         if (rc) return rc;
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
+        if (have && csr && hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out");
     }
     ++h->stat_rounds;
     if (fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
@@ -765,15 +773,63 @@ int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32
         rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters, hint);
         if (rc) return rc;
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
-        if (w > 0) {
+        if (w > 0 && csr) {
+            hdr[8] = hdr[9] = hdr[10] = 0;
+            const int64_t serial = ++h->round_serial;
+            rc = launch_round_csr(h, cap, nullptr, w, d_idx, d_sc, coef_ld, h->pinned_dev, serial);
+            if (rc) return rc;
+            rc = wait_round_done(h, hdr + 7, serial);
+            if (rc) return rc;
+            if (hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out");
+        } else if (w > 0) {
             rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
             if (rc) return rc;
-            HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, ret_bytes, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, sdpcut_sync(h));
         }
     }
     *n_out = w;
     *block = h->pinned;
+    return SDPCUT_OK;
+}
+
+extern "C" {
+
+int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, const void **block,
+                             int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    return round_impl(h, strat, sel_size, coef_ld, false, block, cap_out, n_out, n_total, new_strat, counters);
+}
+
+int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, sdpcut_round_csr_t *out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!out) return sdpcut_fail(h, SDPCUT_EINVAL, "out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    int rc;
+    if (vars_values && (rc = sdpcut_set_point(h, vars_values))) return rc;
+    const void *block = nullptr;
+    const int32_t ld = h->row_len_max;
+    out->row_ld = ld;
+    rc = round_impl(h, strat, sel_size, ld, true, &block, &out->cap, &out->n_out, &out->n_total, &out->new_strat, out->counters);
+    if (rc) return rc;
+    if (!block || out->cap == 0) return SDPCUT_OK;
+    const CsrLayout y = csr_layout(out->cap, ld);
+    const char *b = (const char *)block;
+    const int64_t *hdr = (const int64_t *)b;
+    out->idx = (const int64_t *)(b + y.idx);
+    out->score = (const double *)(b + y.score);
+    out->lam_min = (const double *)(b + y.lam);
+    out->ks = (const int32_t *)(b + y.ks);
+    out->set_inds = (const int32_t *)(b + y.sets);
+    out->n_rows = out->n_out > 0 ? hdr[8] : 0;
+    out->nnz = out->n_out > 0 ? hdr[9] : 0;
+    out->row_entry = (const int32_t *)(b + y.row_entry);
+    out->indptr = (const int32_t *)(b + y.indptr);
+    out->indices = (const int32_t *)(b + y.indices);
+    out->values = (const double *)(b + y.values);
+    out->rhs = (const double *)(b + y.rhs);
     return SDPCUT_OK;
 }
 

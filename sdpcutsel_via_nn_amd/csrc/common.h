@@ -60,6 +60,7 @@ struct sdpcut_ctx {
     bool fuse_keys = true;         // SDPCUT_OPT_FUSE_KEYS (see include/sdpcut.h)
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
+    bool eig_kernel = true;        // SDPCUT_OPT_EIG_KERNEL: eigenvalue-only launches run eig_only_kernel (eig.hip)
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)
     int64_t stat_rounds = 0, stat_fallbacks = 0;   // sdpcut_get_stat
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
@@ -164,6 +165,13 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
 int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
                       int coef_ld, void *block, int64_t hdr_bytes = 64, int64_t done_serial = 0);
 int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n);
+// rows.hip: the round's epilogue in CSR form (sdpcut_round_csr); byte offsets of the block's arrays
+struct CsrLayout { size_t idx, score, lam, rhs, values, ks, sets, row_entry, indptr, indices, bytes; };
+CsrLayout csr_layout(int64_t cap, int ld);
+int launch_round_csr(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, int64_t limit, const int64_t *d_idx, const double *d_score,
+                     int ld, void *block, int64_t serial);
+// eig.hip: lambda_min of every candidate, one launch over all size classes; tk = TopkWs of a feasibility selection or NULL
+int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_stop);
 int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial);   // capi.hip
 int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap, uint32_t need, bool allow_auto, int *stage,
                         bool *auto_out);                                   // capi.hip

@@ -1,0 +1,88 @@
+// Gather of one candidate's slices from the instance tables and its lambda_min -- shared by the
+// scoring kernels (score.hip) and the eigenvalue-only kernel of the feasibility rounds (eig.hip).
+#pragma once
+#include "common.h"
+#include "jacobi.h"
+
+// ------------------------------------------------------------------------------------------
+// gather of one candidate (cut_select_qp.py:529-540 record + :573-575 slices)
+template <int K>
+struct Cand {
+    static constexpr int M = K * (K + 1) / 2;
+    double x[K];
+    double X[M];
+    double q[M];     // Q_slice (already divided by max_elem)
+    double max_elem;
+    double negSM;    // (-S) * max_elem
+};
+
+template <int K>
+__device__ __forceinline__ void load_index_set(int32_t (&s)[K], const int32_t *set, int64_t n, int64_t c)
+{
+#pragma unroll
+    for (int a = 0; a < K; ++a) s[a] = set[(int64_t)a * n + c];
+}
+
+template <int K>
+__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t (&s)[K], const double *vars,
+                                                 const double *Q, int32_t nv, int64_t L, bool want_q)
+{
+    constexpr int M = K * (K + 1) / 2;
+#pragma unroll
+    for (int a = 0; a < K; ++a) cd.x[a] = vars[L + s[a]];
+    int32_t pos[M];
+    {
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            // packed row-major upper-triangle position, cut_select_qp.py:531
+            const int32_t rowbase = nv * s[a] - (s[a] * (s[a] + 1)) / 2;
+#pragma unroll
+            for (int b = a; b < K; ++b) pos[m++] = rowbase + s[b];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) cd.X[m] = vars[pos[m]];
+    if (want_q) {
+        double amax = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            cd.q[m] = Q[pos[m]];
+            amax = fmax(amax, fabs(cd.q[m]));
+        }
+        double me = (double)K * amax;       // :536  (exact: K * |integer-ish|, one rounding)
+        if (me == 0.0) me += 1.0;           // :537
+        cd.max_elem = me;
+        // reference operation order, no contraction:  S = ((0 + q0*X0) + q1*X1) + ...
+        {
+#pragma clang fp contract(off)
+            double S = 0.0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                cd.q[m] = cd.q[m] / me;     // np.divide, :538
+                S = S + cd.q[m] * cd.X[m];  // :575
+            }
+            cd.negSM = (-S) * me;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set, int64_t n, int64_t c,
+                                                 const double *vars, const double *Q, int32_t nv,
+                                                 int64_t L, bool want_q)
+{
+    int32_t s[K];
+    load_index_set<K>(s, set, n, c);
+    gather_candidate<K>(cd, s, vars, Q, nv, L, want_q);
+}
+
+template <int K>
+__device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
+{
+    double a[K + 1][K + 1], v[K + 1][K + 1];
+    fill_lifted<K>(a, cd.x, cd.X);
+    jacobi_eig<K + 1, false>(a, v);
+    return diag_min<K + 1>(a);
+}
+

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "jacobi.h"
+#include "gather.h"
 #include "topk_dev.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -51,88 +52,6 @@ struct ScoreArgs {
     int64_t *strong_out;
     NetDev net;
 };
-
-// ------------------------------------------------------------------------------------------
-// gather of one candidate (cut_select_qp.py:529-540 record + :573-575 slices)
-template <int K>
-struct Cand {
-    static constexpr int M = K * (K + 1) / 2;
-    double x[K];
-    double X[M];
-    double q[M];     // Q_slice (already divided by max_elem)
-    double max_elem;
-    double negSM;    // (-S) * max_elem
-};
-
-template <int K>
-__device__ __forceinline__ void load_index_set(int32_t (&s)[K], const int32_t *set, int64_t n, int64_t c)
-{
-#pragma unroll
-    for (int a = 0; a < K; ++a) s[a] = set[(int64_t)a * n + c];
-}
-
-template <int K>
-__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t (&s)[K], const double *vars,
-                                                 const double *Q, int32_t nv, int64_t L, bool want_q)
-{
-    constexpr int M = K * (K + 1) / 2;
-#pragma unroll
-    for (int a = 0; a < K; ++a) cd.x[a] = vars[L + s[a]];
-    int32_t pos[M];
-    {
-        int m = 0;
-#pragma unroll
-        for (int a = 0; a < K; ++a) {
-            // packed row-major upper-triangle position, cut_select_qp.py:531
-            const int32_t rowbase = nv * s[a] - (s[a] * (s[a] + 1)) / 2;
-#pragma unroll
-            for (int b = a; b < K; ++b) pos[m++] = rowbase + s[b];
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) cd.X[m] = vars[pos[m]];
-    if (want_q) {
-        double amax = 0.0;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            cd.q[m] = Q[pos[m]];
-            amax = fmax(amax, fabs(cd.q[m]));
-        }
-        double me = (double)K * amax;       // :536  (exact: K * |integer-ish|, one rounding)
-        if (me == 0.0) me += 1.0;           // :537
-        cd.max_elem = me;
-        // reference operation order, no contraction:  S = ((0 + q0*X0) + q1*X1) + ...
-        {
-#pragma clang fp contract(off)
-            double S = 0.0;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                cd.q[m] = cd.q[m] / me;     // np.divide, :538
-                S = S + cd.q[m] * cd.X[m];  // :575
-            }
-            cd.negSM = (-S) * me;
-        }
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set, int64_t n, int64_t c,
-                                                 const double *vars, const double *Q, int32_t nv,
-                                                 int64_t L, bool want_q)
-{
-    int32_t s[K];
-    load_index_set<K>(s, set, n, c);
-    gather_candidate<K>(cd, s, vars, Q, nv, L, want_q);
-}
-
-template <int K>
-__device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
-{
-    double a[K + 1][K + 1], v[K + 1][K + 1];
-    fill_lifted<K>(a, cd.x, cd.X);
-    jacobi_eig<K + 1, false>(a, v);
-    return diag_min<K + 1>(a);
-}
 
 // tansig as MATLAB defines it (neural_net_3D.m:77-79): a = 2 / (1 + exp(-2 n)) - 1
 __device__ __forceinline__ double tansig_lib(double n)
@@ -999,201 +918,6 @@ __global__ __launch_bounds__(64) void nn_batch_kernel(NetDev net, int64_t count,
 }
 
 // ------------------------------------------------------------------------------------------
-// Eigen-cut rows of selected candidates (cut_select_qp.py:737-750), one lane per cut.
-template <int K>
-__device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *vars, int32_t nv, int64_t L,
-                                            double *lam_out, double *coef, double *rhs, int64_t *cols)
-{
-    constexpr int M = K * (K + 1) / 2;
-    constexpr int D = K + 1;
-    double x[K], X[M];
-    int32_t s[K];
-#pragma unroll
-    for (int a = 0; a < K; ++a) {
-        s[a] = s5[a];
-        x[a] = vars[L + s[a]];
-        cols[a] = L + s[a];
-    }
-    {
-        int m = 0;
-#pragma unroll
-        for (int a = 0; a < K; ++a) {
-            const int32_t rowbase = nv * s[a] - (s[a] * (s[a] + 1)) / 2;
-#pragma unroll
-            for (int b = a; b < K; ++b) {
-                X[m] = vars[rowbase + s[b]];
-                cols[K + m] = rowbase + s[b];
-                ++m;
-            }
-        }
-    }
-    double a[D][D], v[D][D];
-    fill_lifted<K>(a, x, X);
-    jacobi_eig<D, true>(a, v);
-    // eigenvector of the smallest eigenvalue (first minimum, like LAPACK's ascending order)
-    double lam = a[0][0];
-    double ev[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) ev[i] = v[i][0];
-#pragma unroll
-    for (int j = 1; j < D; ++j) {
-        const bool less = a[j][j] < lam;
-        lam = less ? a[j][j] : lam;
-#pragma unroll
-        for (int i = 0; i < D; ++i) ev[i] = less ? v[i][j] : ev[i];
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) ev[i] = (fabs(ev[i]) <= -SDPCUT_NEG_EIGVAL) ? 0.0 : ev[i];  // :744
-    {
-#pragma clang fp contract(off)
-        int m = 0;
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = (i > 1 ? i : 1); j < D; ++j) {     // :745-746
-                coef[m++] = (i != j) ? ev[i] * ev[j] * 2 : ev[i] * ev[j];
-            }
-        *rhs = -ev[0] * ev[0];
-    }
-    *lam_out = lam;
-}
-
-// count may be an upper bound: if d_limit != NULL only min(count, *d_limit) rows exist (the
-// device-side length of a ranking that the host has not read yet).  coef rows have stride
-// coef_ld >= k + k(k+1)/2 of the largest candidate; cols (stride SDPCUT_ROW_LD) is optional.
-__global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64_t *d_limit, const int64_t *idx,
-                                                      int64_t idx_base, int64_t n_local, const int32_t *set5,
-                                                      const int32_t *ks,
-                                                      const double *vars, int32_t nv, int64_t L, double *lam,
-                                                      double *coef, int coef_ld, double *rhs, int64_t *cols,
-                                                      int32_t *ks_out)
-{
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (d_limit && *d_limit < count) count = *d_limit;
-    if (i >= count) return;
-    const int64_t c = idx[i] - idx_base;
-    if (c < 0 || c >= n_local) {   // a candidate of another shard (sdpcut_shard_finish_round): no row here
-        ks_out[i] = 0;
-        lam[i] = __builtin_nan("");
-        rhs[i] = 0.0;
-        for (int m = 0; m < coef_ld; ++m) coef[i * coef_ld + m] = 0.0;
-        if (cols)
-            for (int m = 0; m < SDPCUT_ROW_LD; ++m) cols[i * SDPCUT_ROW_LD + m] = -1;
-        return;
-    }
-    const int k = ks[c];
-    const int32_t *s5 = set5 + c * 5;
-    double co[SDPCUT_ROW_LD];
-    int64_t cl[SDPCUT_ROW_LD];
-#pragma unroll
-    for (int m = 0; m < SDPCUT_ROW_LD; ++m) { co[m] = 0.0; cl[m] = -1; }
-    ks_out[i] = k;
-    switch (k) {
-    case 2: cut_row_one<2>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    case 3: cut_row_one<3>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    case 4: cut_row_one<4>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    default: cut_row_one<5>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    }
-#pragma unroll
-    for (int m = 0; m < SDPCUT_ROW_LD; ++m) {
-        if (m < coef_ld) coef[i * coef_ld + m] = co[m];
-        if (cols) cols[i * SDPCUT_ROW_LD + m] = cl[m];
-    }
-}
-
-// Epilogue of a fused round (sdpcut_select_round): the rows of the ranking head together with
-// its ids, scores and the four ranking counters go straight into the caller-visible block --
-// pinned host memory mapped into the device, so the stores ARE the device-to-host transfer (no
-// SDMA hand-off, no extra copy launch).  Layout (cap entries): 64 B counters | idx | score | lam |
-// rhs | coef [cap][coef_ld] | ks.  Coefficient rows are staged in LDS and leave as contiguous
-// coalesced stores.  The kernel also zeroes the top-k workspace the NEXT round will use.
-// The sharded round (sdpcut_shard_finish_round) uses it with d_c4 == NULL (all cap entries exist,
-// those of other shards get ks = 0 / lam = NaN) and a header of world x 64 bytes written elsewhere.
-__global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64_t *d_c4, const int64_t *idx,
-                                                        const double *score, int64_t idx_base, int64_t n_local,
-                                                        const int32_t *set5, const int32_t *ks, const double *vars,
-                                                        int32_t nv, int64_t L, int coef_ld, char *block,
-                                                        int64_t hdr_bytes, uint64_t *zero_ptr, int zero_words,
-                                                        int64_t done_serial, uint32_t *done_ticket)
-{
-    __shared__ double tile[64 * SDPCUT_ROW_LD];
-    const int lane = threadIdx.x;
-    for (int w = blockIdx.x * 64 + lane; w < zero_words; w += gridDim.x * 64) zero_ptr[w] = 0ull;
-    int64_t *o_c4 = (int64_t *)block;
-    int64_t *o_idx = (int64_t *)(block + hdr_bytes);
-    double *o_score = (double *)(o_idx + cap);
-    double *o_lam = o_score + cap;
-    double *o_rhs = o_lam + cap;
-    double *o_coef = o_rhs + cap;
-    int32_t *o_ks = (int32_t *)(o_coef + cap * coef_ld);
-    const int64_t first = (int64_t)blockIdx.x * 64;
-    const int64_t i = first + lane;
-    // (requested before the head's length is known: one dependent trip to memory less on the critical path of a
-    // kernel that is a chain of them; an entry beyond the head is never dereferenced)
-    const int64_t gid_any = i < cap ? idx[i] : 0;
-    const double score_any = i < cap ? score[i] : 0.0;
-    int64_t limit = cap;
-    if (d_c4) {
-        if (blockIdx.x == 0 && lane < 7) o_c4[lane] = d_c4[lane];     // counters, strong count, mode (TopkWs::counters)
-        limit = d_c4[3];
-        if (limit > cap) limit = cap;
-    }
-    if (i < limit) {
-        const int64_t gid = gid_any;
-        const int64_t c = gid - idx_base;
-        double co[SDPCUT_ROW_LD];
-        int64_t cl[SDPCUT_ROW_LD];
-#pragma unroll
-        for (int m = 0; m < SDPCUT_ROW_LD; ++m) co[m] = 0.0;
-        double lam = __builtin_nan(""), rhs = 0.0;
-        int k = 0;
-        // ids and scores go out first: the kernel ends in a burst of 0.54 MB over PCIe (~8 us at the link's rate, most of
-        // what the kernel takes beyond its launch) -- what is known before the eigenvectors travels while they are computed
-        o_idx[i] = gid;
-        o_score[i] = score_any;
-        if (c >= 0 && c < n_local) {
-            k = ks[c];
-            const int32_t *s5 = set5 + c * 5;
-            switch (k) {
-            case 2: cut_row_one<2>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            case 3: cut_row_one<3>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            case 4: cut_row_one<4>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            default: cut_row_one<5>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            }
-        }
-        o_lam[i] = lam;
-        o_rhs[i] = rhs;
-        o_ks[i] = k;
-#pragma unroll
-        for (int m = 0; m < SDPCUT_ROW_LD; ++m)
-            if (m < coef_ld) tile[lane * coef_ld + m] = co[m];
-    }
-    wave_lds_sync();
-    const int64_t nlive = (limit - first < 64) ? limit - first : 64;
-    const int total = nlive > 0 ? (int)nlive * coef_ld : 0;
-    for (int w = lane; w < total; w += 64) o_coef[first * coef_ld + w] = tile[w];
-    if (done_serial) {
-        // completion word for the polling host: every workgroup makes its stores to the host block
-        // visible system-wide, then takes a ticket; the last one publishes the round's serial number
-        __threadfence_system();
-        if (lane == 0) {
-            const uint32_t t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == gridDim.x - 1) {
-                __hip_atomic_store(done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next round
-                __threadfence_system();
-                __hip_atomic_store(o_c4 + 7, done_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-}
-
-// LP point: mapped host memory -> device table (sdpcut_set_point)
-__global__ __launch_bounds__(256) void point_copy_kernel(const double *src, double *dst, int64_t n)
-{
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
-}
-
-// ------------------------------------------------------------------------------------------
 // Batched full eigen-decomposition of explicit sub-matrices (twin of _get_eigendecomp).
 template <int K>
 __global__ __launch_bounds__(64) void eig_batch_kernel(int64_t count, const double *xr, const double *Xr,
@@ -1364,6 +1088,13 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
     }
     // the first non-empty size class carries the start event, the last one the stop event
     int first = 0, last = 0;
+    if (flags == SDPCUT_EIG && h->kernel_variant == SDPCUT_KERNEL_MFMA && h->eig_kernel) {
+        // a pure-feasibility scan has its own kernel: one launch over all size classes (eig.hip)
+        if (fuse && fuse->mode != TK_MODE_FEAS)
+            return sdpcut_fail(h, SDPCUT_EINVAL, "score: the selection mode ranks by a measure this launch does not compute");
+        h->timed_score = h->timing != 0 && h->N > 0;
+        return launch_eig_only(h, fuse ? fuse->ws : nullptr, h->timed_score ? h->ev[0] : nullptr, h->timed_score ? h->ev[1] : nullptr);
+    }
     for (int k = 2; k <= SDPCUT_MAX_K; ++k)
         if (h->bucket[k].n > 0) { if (!first) first = k; last = k; }
     h->timed_score = h->timing && first;
@@ -1374,48 +1105,6 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
     if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, strong_out))) return rc;
     if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, strong_out))) return rc;
     if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, strong_out))) return rc;
-    return 0;
-}
-
-int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const int64_t *d_idx, int64_t idx_base,
-                    double *d_lam, double *d_coef, int coef_ld, double *d_rhs, int64_t *d_cols, int32_t *d_ks)
-{
-    if (count == 0) return 0;
-    const int grid = (int)((count + 63) / 64);
-    hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_limit, d_idx, idx_base,
-                       h->N, h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
-                       d_ks);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int launch_point_copy(sdpcut_ctx *h, const double *src_mapped, int64_t n)
-{
-    int64_t g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(point_copy_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, h->stream, src_mapped, h->d_vars, n);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int64_t *d_idx, const double *d_score,
-                      int coef_ld, void *block, int64_t hdr_bytes, int64_t done_serial)
-{
-    if (cap <= 0) return 0;
-    if (done_serial && !h->d_done_ticket) {
-        HIP_TRY(h, hipMalloc((void **)&h->d_done_ticket, 64));
-        HIP_TRY(h, hipMemsetAsync(h->d_done_ticket, 0, 64, h->stream));
-    }
-    uint64_t *zp = nullptr;
-    int zw = 0;
-    int rc = topk_alt_ws(h, &zp, &zw);
-    if (rc) return rc;
-    const int grid = (int)((cap + 63) / 64);
-    hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
-                       h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw, done_serial,
-                       h->d_done_ticket);
-    HIP_TRY(h, hipGetLastError());
-    h->topk_alt_clean = true;
     return 0;
 }
 

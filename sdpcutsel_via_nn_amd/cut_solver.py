@@ -28,6 +28,7 @@ from . import _capi, networks
 _THRES_NEG_EIGVAL = -10 ** (-15)      # cut_select_qp.py:24
 _BIG_M = 1000                         # cut_select_qp.py:26
 _HEAD = 5000                          # _SDP_CUTS_PER_ROUND_MAX (:37): rank-list head fetched eagerly
+_FUSED_HEAD_MAX = 16384               # longest head the fused round (sdpcut_round_csr) assembles
 
 
 def _default_sparse_pair():
@@ -71,13 +72,35 @@ class RankList(Sequence):
     ``a + b`` (cut_select_qcqp.py:79) and slicing return plain lists of entries.
     """
 
-    def __init__(self, owner, binding, kind, total, vars_values, head_idx, head_score, strat=None, sel_size=0):
+    def __init__(self, owner, binding, kind, total, vars_values, head_idx, head_score, strat=None, sel_size=0, fused=None):
         self._owner, self._b, self._kind, self._n = owner, binding, kind, int(total)
         self._vv = vars_values
         self._strat, self._sel_size = strat, sel_size
         self._idx, self._score = head_idx, head_score
         self._have = head_idx.shape[0]
         self._point = binding.point_token
+        # fused round (sdpcut_round_csr): the cuts of the head already sit, assembled, in the scorer's pinned block;
+        # `fused` holds views of it, good until the scorer runs its next round (round_count moves on)
+        self._fused, self._fused_at = fused, binding.scorer.round_count
+        self._head_sets = self._head_ks = None
+        if fused is not None:
+            self._head_sets, self._head_ks = fused["set_inds"].copy(), fused["ks"].copy()
+
+    def fused_rows(self, count, strong_only=False, vars_values=None):
+        """The assembled cuts of the first ``count`` entries if the fused round's block still holds them:
+        (indptr, indices, values, rhs) views, or None (stale block, longer head, another LP point)."""
+        f = self._fused
+        if f is None or self._b.scorer.round_count != self._fused_at or count > self._have:
+            return None
+        if vars_values is not None and vars_values is not self._vv and not np.array_equal(vars_values, self._vv):
+            return None
+        if strong_only:                                   # cut_select_qp.py:725-726
+            stop = np.flatnonzero(self._score[:count] <= 0)
+            if stop.size:
+                count = int(stop[0])
+        r = int(np.searchsorted(f["row_entry"], count))   # cuts of the first `count` entries = a prefix of the block
+        nnz = int(f["indptr"][r])
+        return f["indptr"][:r + 1], f["indices"][:nnz], f["values"][:nnz], f["rhs"][:r]
 
     # -- data access -----------------------------------------------------------------
     def _need(self, upto):
@@ -101,9 +124,21 @@ class RankList(Sequence):
         self._need(count)
         return self._score[:count]
 
+    def _sets(self, lo, hi, loc):
+        """(index sets [m, 5], sizes [m]) of positions [lo, hi): from the fused round's head when it covers them"""
+        if self._head_sets is not None and hi <= self._head_sets.shape[0]:
+            return self._head_sets[lo:hi], self._head_ks[lo:hi]
+        return self._b.sets_of(loc)
+
     def _entry(self, pos):
         idx, score = int(self._idx[pos]), float(self._score[pos])
-        set_inds, Xarr_inds = self._b.agg_entry(idx)
+        if self._b.agg_list is None or isinstance(self._b.agg_list, DeviceAgg):
+            S, ks = self._sets(pos, pos + 1, np.array([idx - self._b.scorer.base], dtype=np.int64))
+            k, n = int(ks[0]), self._b.nb_vars
+            set_inds = [int(v) for v in S[0, :k]]
+            Xarr_inds = [n * set_inds[a] - set_inds[a] * (set_inds[a] + 1) // 2 + set_inds[c] for a in range(k) for c in range(a, k)]
+        else:
+            set_inds, Xarr_inds = self._b.agg_entry(idx)
         if self._kind == 1:
             return FeasEntry((set_inds, score, Xarr_inds, len(set_inds)), idx, self._b)
         L = self._b.nb_lifted
@@ -123,7 +158,7 @@ class RankList(Sequence):
         ids = np.asarray(self._idx[lo:hi], dtype=np.int64)
         loc = ids - b.scorer.base
         scores = np.asarray(self._score[lo:hi], dtype=np.float64).tolist()
-        S_all, ks = b.sets_of(loc)
+        S_all, ks = self._sets(lo, hi, loc)
         out = [None] * (hi - lo)
         for k in np.unique(ks):
             k = int(k)
@@ -153,6 +188,8 @@ class RankList(Sequence):
             if not len(rng):
                 return []
             self._need(max(rng) + 1)
+            if rng.step == 1 and rng.start == 0:
+                return RankListHead(self, rng.stop)
             if rng.step == 1:
                 return self._entries(rng.start, rng.stop)
             return [self._entry(p) for p in rng]
@@ -179,6 +216,43 @@ class RankList(Sequence):
         return _Concat([other, self])
 
 
+class RankListHead(Sequence):
+    """``rank_list[0:count]`` (cut_select_qp.py:181 hands the whole list over, cut_select_qcqp.py:79-97 slices of
+    it): the entries are built when somebody looks at them, and cut generation still finds the rows the fused
+    round assembled for exactly these candidates."""
+
+    def __init__(self, parent, count):
+        self.parent, self._n = parent, int(count)
+        self._list = None
+
+    def _entries(self):
+        if self._list is None:
+            self._list = self.parent._entries(0, self._n)
+        return self._list
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            start, stop, step = key.indices(self._n)
+            if start == 0 and step == 1:
+                return RankListHead(self.parent, stop)
+        return self._entries()[key]
+
+    def __iter__(self):
+        return iter(self._entries())
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __add__(self, other):
+        return _Concat([self, other])
+
+    def __radd__(self, other):
+        return _Concat([other, self])
+
+
 class _Concat(Sequence):
     """Lazy concatenation of rank lists (``rank_list_comb_obj + rank_list_feas_cons``)."""
 
@@ -199,13 +273,15 @@ class _Concat(Sequence):
             start, stop, step = key.indices(n)
             if step != 1:
                 return [self[i] for i in range(start, stop, step)]
-            out, off = [], 0
+            # a slice stays a concatenation of (slices of) its parts: heads of rank lists keep the link to the cuts
+            # their fused rounds assembled (cut_select_qcqp.py:79 slices (A + B)[0:sel_size] before generating)
+            sub, off = [], 0
             for p in self._parts:
                 lo, hi = max(start - off, 0), min(stop - off, len(p))
                 if lo < hi:
-                    out.extend(p[lo:hi])
+                    sub.append(p[lo:hi])
                 off += len(p)
-            return out
+            return _Concat(sub)
         if key < 0:
             key += n
         off = 0
@@ -214,6 +290,9 @@ class _Concat(Sequence):
                 return p[key - off]
             off += len(p)
         raise IndexError(key)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
 
     def __add__(self, other):
         return _Concat(self._parts + [other])
@@ -230,13 +309,18 @@ class _Binding(object):
         self.nb_vars, self.nb_lifted = nb_vars, nb_lifted
         self.rank_serial = 0
         self.point_token = None  # identifies the LP point whose scores the device holds
-        self.point_obj = None    # the array it came from (kept alive: its id cannot be recycled)
-        self.point_vv = None
-        self.point_probe = None
-        self.point_round = None
+        self.point_copy = None   # copy of the LP point last uploaded through this binding
+        self.point_serial = 0
         self.scored = 0
         self.serial = 0
         self.set_arr = None      # [N, 5] index sets as arrays (vectorised entry building)
+
+    def note_point(self, vv, scored=0):
+        """the device now holds LP point ``vv`` (and the measures ``scored`` at it)"""
+        self.point_serial += 1
+        self.point_token = self.point_serial
+        self.point_copy = np.array(vv, dtype=np.float64)
+        self.scored = scored
 
     def agg_entry(self, idx):
         if self.agg_list is not None:
@@ -402,28 +486,27 @@ class GpuCutSelectionMixin(object):
     def _gpu_point(b, vars_values, flags, cut_round=None):
         """Make ``vars_values`` the device's LP point and score what ``flags`` asks for.
 
-        The upload is skipped only when the SAME array object (kept alive by the binding, so
-        its identity cannot be recycled) is presented again for the same round; a strided probe
-        of 64 entries guards against in-place edits of that object.  No hashing of the whole
-        point (4 MB at n = 1000) per call."""
+        The upload is skipped only when the point equals -- entry by entry -- the copy kept of the last one
+        uploaded through this binding (an in-place edit of the caller's array is a new point); the upload
+        itself is an asynchronous copy out of pinned staging, so a redundant one costs little.
+        :meth:`invalidate_point` forces the next call to upload."""
         vv = vars_values if (isinstance(vars_values, np.ndarray) and vars_values.dtype == np.float64 and
                              vars_values.flags.c_contiguous) else np.ascontiguousarray(vars_values, dtype=np.float64)
-        step = max(1, vv.shape[0] // 64)
-        same = ((b.point_obj is vars_values or b.point_vv is vars_values) and (cut_round is None or b.point_round is None or cut_round == b.point_round)
-                and np.array_equal(vv[::step], b.point_probe))
+        same = b.point_copy is not None and b.point_copy.shape == vv.shape and np.array_equal(vv, b.point_copy)
         if not same:
             b.scorer.set_point(vv)
-            b.point_serial = getattr(b, "point_serial", 0) + 1
-            b.point_token = b.point_serial
-            b.point_obj, b.point_vv, b.point_probe, b.scored = vars_values, vv, vv[::step].copy(), 0
-            b.point_round = cut_round
-        elif cut_round is not None and b.point_round is None:
-            b.point_round = cut_round
+            b.note_point(vv)
         need = flags & ~b.scored
         if need:
             b.scorer.score(need)
             b.scored |= need
         return vv
+
+    def invalidate_point(self):
+        """Forget which LP point the device holds: the next selection / generation uploads its point whatever it is
+        (for callers that change device state behind the mixin's back, e.g. through the Scorer directly)."""
+        for b in getattr(self, "_gpu_bindings", {}).values():
+            b.point_copy, b.scored = None, 0
 
     # ------------------------------------------------------------------ a7-a9 selection
     def _sel_eigcut_by_ordering_on_measure(self, strat, vars_values, cut_round, sel_size=0):
@@ -449,13 +532,24 @@ class GpuCutSelectionMixin(object):
         flags = {1: _capi.EIG, 2: _capi.NN, 4: _capi.EIG | _capi.NN}[strat]
         if N == 0:
             return []       # strat 4 included: sel_size is clamped to 0 and the reference falls through
-        vv = self._gpu_point(b, vars_values, flags, cut_round)
         # head fetched eagerly: what the loop can consume (sel_size is only passed for strat 4;
-        # for 1 / 2 the cap of :37 bounds it).  Heads <= 8192 take the device's top-k select path.
+        # for 1 / 2 the cap of :37 bounds it)
         head = min(N, sel_size if (strat == 4 and sel_size > 0) else _HEAD)
-        idx, score, total, new_strat, counters = b.scorer.rank(strat, sel_size, head)
+        vv = vars_values if (isinstance(vars_values, np.ndarray) and vars_values.dtype == np.float64 and
+                             vars_values.flags.c_contiguous) else np.ascontiguousarray(vars_values, dtype=np.float64)
+        fused = None
+        if 1 <= head <= _FUSED_HEAD_MAX and not (strat == 4 and sel_size == 0):
+            # ONE library call for the whole separation step (cut_select_qp.py:165-182): LP point up, scores, ranking
+            # AND the assembled cuts of the head, which _gen_eigcuts_selected then only hands to the LP
+            fused = b.scorer.round_csr(strat, head, point=vv)
+            b.note_point(vv, flags)
+            idx, score = fused["idx"].copy(), fused["score"].copy()
+            total, new_strat, counters = fused["n_total"], fused["new_strat"], fused["counters"]
+        else:
+            vv = self._gpu_point(b, vv, flags, cut_round)
+            idx, score, total, new_strat, counters = b.scorer.rank(strat, sel_size, head)
         b.rank_serial += 1
-        rl = RankList(self, b, 1 if strat == 1 else 2, total, vv, idx, score, strat=strat, sel_size=sel_size)
+        rl = RankList(self, b, 1 if strat == 1 else 2, total, vv, idx, score, strat=strat, sel_size=sel_size, fused=fused)
         rl.counters = counters
         if strat == 4:
             # the reference divides by sel_size and swallows the ZeroDivisionError, falling
@@ -475,7 +569,31 @@ class GpuCutSelectionMixin(object):
             return 0
         # (binding, candidate indices, point) groups in list order; most lists have one group
         groups, vv = None, vars_values
+        if isinstance(rank_list, _Concat):
+            # (A + B)[0:sel_size] of the QCQP round: the cuts of each part, in list order, if every part still has them
+            blocks, left = [], sel_size
+            for part in rank_list._parts:
+                if left <= 0:
+                    break
+                rl = part.parent if isinstance(part, RankListHead) else part
+                csr = None
+                if isinstance(rl, RankList):
+                    csr = rl.fused_rows(min(left, len(part)), strong_only=opt_sel and strong_only and rl._kind != 1,
+                                        vars_values=vars_values if rl._kind == 1 else None)
+                if csr is None:
+                    blocks = None
+                    break
+                blocks.append(csr)
+                left -= min(left, len(part))
+            if blocks is not None:
+                return sum(self._gpu_add_csr(c, pair) for c in blocks)
+        if isinstance(rank_list, RankListHead):
+            rank_list, sel_size = rank_list.parent, min(sel_size, len(rank_list))
         if isinstance(rank_list, RankList):
+            csr = rank_list.fused_rows(sel_size, strong_only=opt_sel and strong_only,
+                                       vars_values=vars_values if feas_sel else None)
+            if csr is not None:
+                return self._gpu_add_csr(csr, pair)
             idx, vv = rank_list.ids(sel_size), rank_list._vv
             if opt_sel and strong_only:                       # :725-726
                 stop = np.nonzero(rank_list.scores(sel_size) <= 0)[0]
@@ -530,6 +648,21 @@ class GpuCutSelectionMixin(object):
             rhs_out.append(float(rhs[c]))
         store.add(lin_expr=rows, rhs=rhs_out, senses=["G"] * len(rows))
         return len(rows)
+
+    def _gpu_add_csr(self, csr, pair):
+        """Hand a block of assembled cuts to the LP: as arrays when the row store takes them (``add_csr``), else as the
+        reference's per-row objects (cut_select_qp.py:747-754).  The arrays are copied: they are views of the scorer's
+        pinned block, which the next round overwrites."""
+        indptr, ind, val, rhs = csr
+        r = rhs.shape[0]
+        store = self._my_prob.linear_constraints
+        if hasattr(store, "add_csr"):
+            store.add_csr(np.array(indptr, dtype=np.int64), np.array(ind, dtype=np.int64), np.array(val), np.array(rhs), "G")
+            return r
+        ptr, ind, val = indptr.tolist(), ind.tolist(), val.tolist()
+        rows = [pair(ind=ind[ptr[c]:ptr[c + 1]], val=val[ptr[c]:ptr[c + 1]]) for c in range(r)]
+        store.add(lin_expr=rows, rhs=rhs.tolist(), senses=["G"] * r)
+        return r
 
     def _gen_from_entries(self, entries, feas_sel, vars_values, pair):
         """Generic path for entries that do not carry a candidate index (random strategy, foreign
@@ -757,7 +890,7 @@ class CutSolverQCQP(CutSolver):
             return strat, rank_list, nb, 0
         # :85-92 counters, from the device arrays instead of a Python loop over N tuples
         nb_opt_cuts = int(np.count_nonzero(comb_obj.scores() > _BIG_M)) if len(comb_obj) else 0
-        nb_cuts_combined = sum(1 for e in rank_list if isinstance(e[0], int))
+        nb_cuts_combined = n_obj      # :90-92 counts the entries whose first field is an int: the objective cover's (optimality / combined entries)
         rest = sel_size - nb_cuts_combined
         nb_a = self._gen_eigcuts_selected(1, rest, feas_cons[0:rest], vars_values=vars_values)
         nb_b = self._gen_eigcuts_selected(strat_old, nb_cuts_combined, comb_obj[0:nb_cuts_combined],

@@ -78,20 +78,10 @@ def test_replay_of_the_reference_trajectory(path):
             assert np.all(np.abs(res["score"] - ref_score) <= tol), (r, np.abs(res["score"] - ref_score).max())
             same = res["idx"] == ref_ids
             n_set = int(np.setdiff1d(res["idx"], ref_ids).size)
-            if not same.all():
-                # positions that differ must lie inside runs of equal reference scores (ties, whose order in
-                # the reference is rounding noise); ids selected by one side only must sit in the run that
-                # reaches the end of the head
-                bad = np.flatnonzero(~same)
-                for b in bad:
-                    lo, hi = b, b
-                    while lo > 0 and abs(ref_score[lo - 1] - ref_score[b]) <= tol[b]:
-                        lo -= 1
-                    while hi + 1 < w and abs(ref_score[hi + 1] - ref_score[b]) <= tol[b]:
-                        hi += 1
-                    assert hi > lo, (r, int(b))
-                    if res["idx"][b] not in ref_ids[lo:hi + 1]:
-                        assert hi == w - 1, (r, int(b))
+            # the reference's ORDER, position by position (rounds 1 and 2 observed 0 differing positions in all
+            # 160 000; a swap inside a run of near-equal scores would be a regression of the eigen-solver's
+            # arithmetic, so none is tolerated)
+            assert same.all(), (r, strat, np.flatnonzero(~same)[:10].tolist())
             nb_cuts = int((res["lam"] < -1e-15).sum())
             assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
             report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "
@@ -99,7 +89,7 @@ def test_replay_of_the_reference_trajectory(path):
                                                                         int((~same).sum()), n_set, nb_cuts))
         out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r02_config3_replay.txt"), "a") as f:
+        with open(os.path.join(out_dir, "r03_config3_replay.txt"), "a") as f:
             f.write("\n".join(report) + "\n")
     finally:
         sc.close()

@@ -327,3 +327,38 @@ def test_qcqp_loop_random_strategy(pkg):
                                               nb_rounds_cuts=3)
     assert sel == 9 and len(objs) == 4 and len(cuts) == 4 and opt == [0, 0, 0, 0]
     assert all(b >= a - 1e-9 for a, b in zip(objs, objs[1:]))
+
+
+# ----------------------------------------------------------------------------- handle reuse (capi.hip:504)
+def test_handle_rebound_to_a_larger_instance_after_a_fused_round(pkg, oracle):
+    """Fused round on n = 20, the SAME handle re-bound to n = 100 (the pinned staging block of the LP point
+    grows), fused rounds again: results against the oracle both times.  Round 2's sdpcut_set_point freed the
+    completion ticket of the round epilogue when the staging block grew and kept the dangling pointer."""
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        for nb_vars, count, seed in ((20, 3000, 11), (100, 40000, 12), (20, 3000, 13), (100, 40000, 14)):
+            wl = synthetic.make_workload(nb_vars=nb_vars, k=3, count=count, seed=seed)
+            L = nb_vars * (nb_vars + 1) // 2
+            sc.set_instance(nb_vars, wl["Q_arr"])
+            sc.set_candidates(wl["set_inds"], wl["ks"])
+            vv = wl["vars_values"]
+            si = wl["set_inds"][:, :3]
+            obj = oracle.opt_score_batch(3, si, nb_vars, vv, wl["Q_arr"])
+            eig = oracle.eigmin_batch(3, vv[L:][si], vv[:L][oracle.triu_positions(si, nb_vars)])
+            for strat in (4, 1, 2):
+                for rep in range(3):                   # several epilogues on the (possibly re-allocated) ticket
+                    r = sc.select_round(strat, 500, point=vv)
+                sc.score(_capi.EIG | _capi.NN)
+                d_eig, d_obj = sc.get_scores()
+                assert np.abs(d_eig - eig).max() <= 2e-13
+                order, ref_score, ref_strat, _ = oracle.rank_arrays(strat, d_obj, d_eig, 500)
+                w = min(500, order.shape[0])
+                assert np.array_equal(r["idx"], order[:w]), (nb_vars, strat)
+                assert np.array_equal(r["score"], ref_score[:w] + 0.0) and r["new_strat"] == ref_strat
+                lam, coef, rhs, cols, ks = sc.cut_rows(order[:w])
+                assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :r["coef"].shape[1]])
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+    finally:
+        sc.close()

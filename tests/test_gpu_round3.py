@@ -1,0 +1,294 @@
+"""GPU tests of the round-3 additions (run with -m gpu on an MI355X): the eigenvalue-only kernel of the
+feasibility rounds (csrc/eig.hip) against the scoring kernels' eigenvalue branch and the oracle, on single-size
+and mixed-size lists, with and without the selection's leading-digit histogram."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sdpcutsel_via_nn_amd as p
+    return p
+
+
+def _mixed_workload(nb_vars, sizes, count, seed):
+    """index sets of mixed sizes in one list (caller order interleaves the classes)"""
+    from sdpcutsel_via_nn_amd import synthetic
+    Q_arr, vv, rng = synthetic.make_instance(nb_vars, seed)
+    ks = rng.choice(np.asarray(sizes, dtype=np.int32), size=count)
+    S = np.full((count, 5), -1, dtype=np.int32)
+    for k in sizes:
+        m = np.flatnonzero(ks == k)
+        S[m, :k] = synthetic.random_index_sets(nb_vars, int(k), m.size, rng)
+    return Q_arr, vv, S, ks.astype(np.int32)
+
+
+@pytest.mark.parametrize("sizes,count,nb_vars", [((3,), 10 ** 6, 100), ((2, 3, 4), 300000, 60), ((2, 3, 4, 5), 200000, 40),
+                                                 ((5,), 70000, 30), ((2,), 1000, 20), ((4, 2), 257, 25)])
+def test_eig_only_kernel_bit_equal_to_the_scoring_kernels(pkg, oracle, sizes, count, nb_vars):
+    """lambda_min from eig_only_kernel == lambda_min from score_mfma_kernel (eigenvalue branch and full launch) bit for
+    bit -- the same Jacobi template -- and within 2e-13 of LAPACK; every size mix, ragged last tiles included."""
+    from sdpcutsel_via_nn_amd import _capi
+    Q_arr, vv, S, ks = _mixed_workload(nb_vars, sizes, count, seed=21 + len(sizes))
+    L = nb_vars * (nb_vars + 1) // 2
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(nb_vars, Q_arr)
+        sc.set_candidates(S, ks)
+        out = {}
+        for name, opt, flags in (("eig_kernel", 1, _capi.EIG), ("mfma_branch", 0, _capi.EIG), ("mfma_full", 0, _capi.EIG | _capi.NN)):
+            sc.set_option(_capi.OPT_EIG_KERNEL, opt)
+            sc.set_point(vv)
+            sc.score(flags)
+            out[name] = sc.get_scores(obj=False)[0]
+        assert np.array_equal(out["eig_kernel"], out["mfma_branch"])
+        assert np.array_equal(out["eig_kernel"], out["mfma_full"])
+        pick = np.unique(np.concatenate([np.arange(min(count, 3000)), count - 1 - np.arange(min(count, 3000))]))
+        for k in sizes:
+            m = pick[ks[pick] == k]
+            si = S[m, :k]
+            ref = oracle.eigmin_batch(int(k), vv[L:][si], vv[:L][oracle.triu_positions(si, nb_vars)])
+            assert np.abs(out["eig_kernel"][m] - ref).max() <= 2e-13, int(k)
+    finally:
+        sc.close()
+
+
+@pytest.mark.parametrize("sizes,count,nb_vars,sel", [((3,), 10 ** 6, 100, 5000), ((2, 3, 4), 300000, 60, 5000),
+                                                     ((2, 3, 4, 5), 200000, 40, 700), ((3, 4), 9000, 30, 12000)])
+def test_feasibility_round_through_the_eig_kernel(pkg, oracle, sizes, count, nb_vars, sel):
+    """A fused feasibility round (sdpcut_round_view, strategy 1): the eigenvalue kernel counts the leading digit of the
+    selection keys; ids / scores / rows == the round with the option off == the oracle's ranking of the device's values."""
+    from sdpcutsel_via_nn_amd import _capi
+    Q_arr, vv, S, ks = _mixed_workload(nb_vars, sizes, count, seed=5)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(nb_vars, Q_arr)
+        sc.set_candidates(S, ks)
+        res = {}
+        for opt in (1, 0):
+            sc.set_option(_capi.OPT_EIG_KERNEL, opt)
+            res[opt] = sc.select_round(1, sel, point=vv)
+        eig = sc.get_scores(obj=False)[0]
+        order, ref_score, _, _ = oracle.rank_arrays(1, None, eig, sel)
+        w = min(sel, order.shape[0])
+        for opt in (1, 0):
+            r = res[opt]
+            assert r["n_total"] == order.shape[0] and r["idx"].shape[0] == w
+            assert np.array_equal(r["idx"], order[:w]) and np.array_equal(r["score"], ref_score[:w] + 0.0)
+            assert r["counters"]["nb_violated"] == order.shape[0]
+        for f in ("lam", "coef", "rhs", "ks"):
+            assert np.array_equal(res[1][f], res[0][f]), f
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+    finally:
+        sc.close()
+
+
+def test_feasibility_rounds_of_the_reference_trajectory_through_the_eig_kernel(pkg):
+    """The fifteen pure-feasibility rounds the reference ran on spar125-075-1, dim 4 (rounds 6..20 of
+    tests/golden/rounds_spar125_075_1_d4_s4.npz): the eigenvalue kernel + selection return the reference's ids in the
+    reference's order (the replay test covers all rounds; this one pins WHICH kernel served them)."""
+    from sdpcutsel_via_nn_amd import _capi, harness
+    g = np.load(os.path.join(GOLDEN, "rounds_spar125_075_1_d4_s4.npz"))
+    inst = harness.parse_boxqp(os.path.join(GOLDEN, "instances", "spar125-075-1.in"))
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(4)
+        sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+        assert sc.set_candidates_cover(inst["adj"], 4) == int(g["nb_subproblems"])
+        sc.set_option(_capi.OPT_TIMING, 1)
+        seen = 0
+        for r in range(1, int(g["rounds_done"]) + 1):
+            p = "r%02d_" % r
+            if int(g[p + "strat"]) != 1:
+                continue
+            res = sc.select_round(1, int(g["sel_size"]), point=g[p + "vars"])
+            assert np.array_equal(res["idx"], g[p + "ids"].astype(np.int64)), r
+            assert np.abs(res["score"] - g[p + "score"]).max() <= 2e-13
+            assert sc.last_timing()[0] > 0.0
+            seen += 1
+        assert seen >= 10
+    finally:
+        sc.close()
+
+
+# ----------------------------------------------------------------------------- the round with assembled cuts (sdpcut_round_csr)
+def _padded_reference(sc, strat, sel, vv):
+    """the same round through sdpcut_round_view + sdpcut_cut_rows (padded rows, columns from the library)"""
+    r = sc.select_round(strat, sel, point=vv)
+    lam, coef, rhs, cols, ks = sc.cut_rows(r["idx"] - sc.base)
+    return r, lam, coef, rhs, cols, ks
+
+
+@pytest.mark.parametrize("sizes,count,nb_vars,sel", [((3,), 10 ** 6, 100, 5000), ((2, 3, 4), 300000, 60, 5000),
+                                                     ((2, 3, 4, 5), 200000, 40, 700), ((3, 4), 9000, 30, 12000),
+                                                     ((2, 5), 3000, 30, 5000), ((4,), 130, 12, 64), ((3,), 40000, 50, 16384)])
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_round_csr_equals_the_padded_rows(pkg, sizes, count, nb_vars, sel, strat):
+    """sdpcut_round_csr: head == sdpcut_round_view's; the CSR block == the cuts of _gen_eigcuts_selected built from the
+    padded rows on the host (kept iff lam < -1e-15, columns [L + i] + Xarr_inds, cut_select_qp.py:739-750), bit for bit."""
+    from sdpcutsel_via_nn_amd import _capi
+    from sdpcutsel_via_nn_amd.cut_solver import rows_to_csr
+    Q_arr, vv, S, ks_all = _mixed_workload(nb_vars, sizes, count, seed=31)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(nb_vars, Q_arr)
+        sc.set_candidates(S, ks_all)
+        r, lam, coef, rhs, cols, ks = _padded_reference(sc, strat, sel, vv)
+        c = sc.round_csr(strat, sel, point=vv, copy=True)
+        assert np.array_equal(c["idx"], r["idx"]) and np.array_equal(c["score"], r["score"])
+        assert c["n_total"] == r["n_total"] and c["new_strat"] == r["new_strat"] and c["counters"] == r["counters"]
+        assert np.array_equal(c["lam"], lam) and np.array_equal(c["ks"], ks)
+        assert np.array_equal(c["set_inds"], S[c["idx"]])
+        keep = np.flatnonzero(lam < -1e-15)
+        assert np.array_equal(c["row_entry"], keep)
+        indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
+        assert np.array_equal(c["indptr"], indptr) and np.array_equal(c["indices"], ind) and np.array_equal(c["values"], val)
+        assert np.array_equal(c["rhs"], rhs[keep])
+        if strat == 2 and count >= 3000:
+            assert 0 < keep.size < c["idx"].shape[0]       # the optimality head holds non-violated entries: the compaction is exercised
+        # the same point again without an upload (vars_values = NULL)
+        c2 = sc.round_csr(strat, sel, point=None, copy=True)
+        for f in ("idx", "score", "indptr", "indices", "values", "rhs", "row_entry"):
+            assert np.array_equal(c[f], c2[f]), f
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+    finally:
+        sc.close()
+
+
+def test_round_csr_general_regime_and_short_lists(pkg, oracle):
+    """combined strategy with fewer strong candidates than the quota (every entry visited), a feasibility list shorter
+    than the head asked for, and an all-PSD point (no cut at all)"""
+    from sdpcutsel_via_nn_amd import synthetic
+    from sdpcutsel_via_nn_amd.cut_solver import rows_to_csr
+    wl = synthetic.make_workload(nb_vars=40, k=3, count=60000, seed=9)
+    n, L = 40, 820
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(3)
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        x = wl["vars_values"][L:]
+        iu = np.triu_indices(n)
+        psd = np.concatenate([np.minimum(x[iu[0]], x[iu[1]]), x])          # X = min(x_i, x_j) is PSD: nothing violated
+        for vv, sel in ((wl["vars_values"], 5000), (psd, 5000), (0.999 * psd + 0.001 * wl["vars_values"], 3000)):
+            for strat in (4, 1, 2):
+                r, lam, coef, rhs, cols, ks = _padded_reference(sc, strat, sel, vv)
+                c = sc.round_csr(strat, sel, point=vv, copy=True)
+                assert np.array_equal(c["idx"], r["idx"]) and np.array_equal(c["score"], r["score"]) and c["new_strat"] == r["new_strat"]
+                keep = np.flatnonzero(lam < -1e-15)
+                indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
+                assert np.array_equal(c["row_entry"], keep) and np.array_equal(c["indptr"], indptr)
+                assert np.array_equal(c["indices"], ind) and np.array_equal(c["values"], val) and np.array_equal(c["rhs"], rhs[keep])
+        r = sc.round_csr(1, 5000, point=psd)
+        assert r["idx"].shape[0] == 0 and r["rhs"].shape[0] == 0 and r["n_total"] == 0 and r["indptr"].tolist() == [0]
+    finally:
+        sc.close()
+
+
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_dropin_pair_hands_over_the_fused_rows(pkg, strat):
+    """_sel_eigcut_by_ordering_on_measure + _gen_eigcuts_selected (cut_select_qp.py:165-182) on the mixin: the selection
+    runs the fused round and the generation consumes its assembled cuts; the LP's row store ends up with exactly the rows
+    the two-call route (rank, then sdpcut_cut_rows + host assembly) produces -- also for a shorter prefix, for strong_only,
+    through the reference's per-row objects, and after the block went stale."""
+    from sdpcutsel_via_nn_amd import harness, synthetic
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolver, AggArrays, RankList
+    Q_arr, vv, S, ks = _mixed_workload(50, (2, 3, 4), 120000, seed=77)
+    n, L = 50, 1275
+
+    def solver():
+        cs = CutSolver()
+        cs.set_instance(n, Q_arr, AggArrays(S, ks, n, Q_arr), 4, my_prob=harness.LinearRelaxation(np.zeros(L + n)))
+        return cs
+
+    def run(cs, sel, fused, strong_only=False, store=None):
+        if store is not None:
+            cs._my_prob.linear_constraints = store
+        out = cs._sel_eigcut_by_ordering_on_measure(strat, vv, 1, **({"sel_size": sel} if strat == 4 else {}))
+        rl = out[1] if strat == 4 else out
+        assert isinstance(rl, RankList) and rl._fused is not None
+        if not fused:
+            rl._fused = None                  # the two-call route: ids -> sdpcut_cut_rows -> rows_to_csr on the host
+        nb = cs._gen_eigcuts_selected(strat, sel, rl, strong_only=strong_only, vars_values=vv)
+        return nb, cs._my_prob.linear_constraints
+
+    for sel, strong_only in ((5000, False), (1234, False), (5000, True)):
+        a, b = solver(), solver()
+        nb_a, st_a = run(a, sel, True, strong_only)
+        nb_b, st_b = run(b, sel, False, strong_only)
+        assert nb_a == nb_b == st_a.get_num() > 0
+        da, ca, la = st_a.csr_parts()
+        db, cb, lb = st_b.csr_parts()
+        assert np.array_equal(da, db) and np.array_equal(ca, cb) and np.array_equal(la, lb)
+        assert st_a.rhs == st_b.rhs and st_a.senses == st_b.senses
+        if strong_only and strat != 1:
+            assert nb_a < 5000
+
+    class RefStore(object):                   # the reference's LP surface: only add(lin_expr=, rhs=, senses=)
+        def __init__(self):
+            self.rows, self.rhs = [], []
+        def add(self, lin_expr=(), rhs=(), senses=()):
+            self.rows.extend(lin_expr); self.rhs.extend(rhs)
+            assert len(senses) == len(lin_expr) and all(s == "G" for s in senses)
+    c = solver()
+    c._sparse_pair = harness.SparsePair
+    nb_c, st_c = run(c, 5000, True, store=RefStore())
+    a = solver()
+    nb_a, st_a = run(a, 5000, True)
+    rows_a = st_a.rows
+    assert nb_c == nb_a == len(st_c.rows)
+    assert all(x.ind == y.ind and x.val == y.val for x, y in zip(st_c.rows, rows_a)) and st_c.rhs == st_a.rhs
+
+    # a later round on the same scorer overwrites the pinned block: the older list must notice
+    d = solver()
+    out = d._sel_eigcut_by_ordering_on_measure(strat, vv, 1, **({"sel_size": 5000} if strat == 4 else {}))
+    rl_old = out[1] if strat == 4 else out
+    vv2 = harness.random_mccormick_point(n, np.random.default_rng(3))
+    d._sel_eigcut_by_ordering_on_measure(strat, vv2, 2, **({"sel_size": 5000} if strat == 4 else {}))
+    assert rl_old.fused_rows(5000) is None
+    nb_d = d._gen_eigcuts_selected(strat, 5000, rl_old, vars_values=vv)
+    dd, cd, ld_ = d._my_prob.linear_constraints.csr_parts()
+    da, ca, la = st_a.csr_parts()
+    assert nb_d == nb_a and np.array_equal(dd, da) and np.array_equal(cd, ca)
+
+
+def test_qcqp_round_keeps_the_fused_rows_through_slices(pkg, oracle, golden_qcqp):
+    """CutSolverQCQP.select_and_generate_round slices both rank lists (cut_select_qcqp.py:79-97); the slices still lead
+    to the cuts their fused rounds assembled (no second trip to the device: sdpcut_cut_rows is never called), and the
+    rows are the oracle's QCQP round's."""
+    from conftest import agg_from_arrays
+    from sdpcutsel_via_nn_amd import _capi, harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolverQCQP
+    g = golden_qcqp
+    n = int(g["nb_vars"])
+    L = n * (n + 1) // 2
+    agg_o = agg_from_arrays(oracle, g["obj_set_inds"], g["obj_k"], n, g["Q_arr"])
+    agg_c = agg_from_arrays(oracle, g["cons_set_inds"], g["cons_k"], n, g["Q_arr"])
+    calls = []
+    orig = _capi.Scorer.cut_rows
+    _capi.Scorer.cut_rows = lambda self, idx: calls.append(len(idx)) or orig(self, idx)
+    try:
+        for strat, sel in ((4, 40), (2, 7), (1, 40)):
+            cs = CutSolverQCQP()
+            lp = harness.LinearRelaxation(np.zeros(L + n))
+            cs.set_instance(n, g["Q_arr"], agg_o, dim=3, my_prob=lp)
+            new_strat, rank_list, nb_cuts, nb_opt = cs.select_and_generate_round(strat, g["vars"], 1, sel, agg_o, agg_c)
+            ref = oracle.qcqp_round(agg_o, agg_c, L, strat, g["vars"], sel)
+            assert nb_cuts == ref["nb_sdp_cuts"] == lp.linear_constraints.get_num()
+            for row, (ind, val) in zip(lp.linear_constraints.rows, ref["rows"]):
+                assert row.ind == list(ind)
+                assert np.abs(np.array(row.val) - np.array(val, dtype=np.float64)).max() <= 1e-9
+            q = "s%d_sel%d" % (strat, sel)
+            assert [isinstance(e[0], int) for e in rank_list] == g[q + "_is_obj"].tolist()
+        assert calls == []
+    finally:
+        _capi.Scorer.cut_rows = orig
