@@ -280,6 +280,8 @@ def main():
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
+    ap.add_argument("--no-pinned-point", action="store_true",
+                    help="A/B (c4 configs): hand the LP point over in an ordinary host array instead of the handle's pinned buffer")
     ap.add_argument("--two-calls", action="store_true", help="A/B: sdpcut_set_point + sdpcut_select_round_view instead of sdpcut_round_view")
     ap.add_argument("--coop", action="store_true", help="A/B: cooperative launch of the fused selection kernel (+20 us per round)")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
@@ -360,6 +362,13 @@ def main():
         return sc, Q_arr, vv, sets
 
     sc, Q_arr, vv_host, sets_host = make_scorer(K, n_local, 7 + rank, rank * n_local)
+    pinned_point = args.config != "c2" and not args.no_pinned_point and not args.device_point
+    if pinned_point:
+        # n = 1000: the LP point is 4 MB.  A caller that lets its LP solver write the solution into the handle's pinned
+        # staging block (sdpcut_point_buffer) saves the library's host copy of it (~110 us per round)
+        vv_pageable = vv_host
+        vv_host = sc.point_buffer()
+        vv_host[:] = vv_pageable
     d_vars = torch.from_numpy(vv_host).to(device) if args.device_point else None
     sel = None
     if world > 1 or force_sharded:
@@ -436,6 +445,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    phases = None
+    if sel is not None:
+        # Where a sharded step goes (every rank runs the loop -- it contains the collective --, rank 0 reports): device
+        # time between events on the stream the library and the collective share, host time around each call.  Untimed
+        # extra steps after the measured region; the events cost the host a few microseconds each.
+        from sdpcutsel_via_nn_amd import _capi as capi
+        ops = sel.ops
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = np.zeros(8)
+        n_ph = 30
+        for _ in range(n_ph):
+            t0 = time.perf_counter()
+            sc.set_point(vv_host)
+            t1 = time.perf_counter()
+            ev[0].record()
+            rec = ops.shard_head(capi.PART_STRONG, SEL)
+            ev[1].record()
+            t2 = time.perf_counter()
+            allrec = sel._all_gather(rec)
+            ev[2].record()
+            t3 = time.perf_counter()
+            ops.shard_finish_enqueue(world, SEL, allrec, SEL)
+            ev[3].record()
+            t4 = time.perf_counter()
+            ops.shard_finish_wait()
+            t5 = time.perf_counter()
+            torch.cuda.synchronize()
+            acc += (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3,
+                    ev[2].elapsed_time(ev[3]) * 1e-3)
+        acc *= 1e6 / n_ph
+        phases = {"steps": n_ph, "rank": 0,
+                  "host_us": {"set_point": acc[0], "shard_head_enqueue": acc[1], "all_gather_enqueue": acc[2], "finish_enqueue": acc[3],
+                              "finish_wait": acc[4]},
+                  "device_us": {"score_and_head": acc[5], "all_gather": acc[6], "merge_and_rows": acc[7]},
+                  "note": "score_and_head = point copy + score kernel + per-shard top-k into the packed record; all_gather = %d records of "
+                          "%d bytes (%s); merge_and_rows = replicated merge + eigen-cut rows of the own entries written to pinned host "
+                          "memory; finish_wait = the round's one host wait" % (world, (8 + 2 * SEL) * 8, backend if use_dist else "no collective")}
     if rank == 0:
         total = n_local * world * args.steps
         k_ms = float(np.mean(kernel_ms))
@@ -451,9 +497,13 @@ def main():
             "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["text"], "config": args.config, "candidates_per_gpu": n_local, "nb_vars": nb_vars, "k": K,
                        "sel_size": SEL, "kernel": args.kernel, "strategy": 4,
-                       "bracket": "device point -> host results" if args.device_point else "host point -> host results"},
+                       "bracket": "device point -> host results" if args.device_point else
+                                  ("LP point in the handle's pinned buffer (sdpcut_point_buffer) -> host results" if pinned_point
+                                   else "host point -> host results")},
             "roofline": roofline(K, n_local, k_ms, traffic, counts_digit=not args.no_fuse_keys),
         }
+        if phases is not None:
+            out["phases"] = phases
         out["roofline"]["kernel_ms_samples"] = len(kernel_ms)
         out["config"]["selection_fallbacks"] = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)       # rounds answered by the full-sort path
         out["roofline"]["traffic_source"] = ("profiles/score_kernel_traffic.json (rocprofv3 --pmc passes of this kernel at "
@@ -486,6 +536,7 @@ def main():
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
         if world == 1 and not args.no_cpu_baseline:
+            vv_host = np.array(vv_host)     # (detach from the handle's pinned buffer: worker processes pickle it)
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample
                 m = min(args.cpu_sample, n_local)
                 sets_host = synthetic.philox_index_sets(nb_vars, K, np.arange(m), seed=7)

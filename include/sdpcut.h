@@ -51,6 +51,11 @@ enum { SDPCUT_STRAT_FEAS = 1, SDPCUT_STRAT_OPT = 2, SDPCUT_STRAT_COMB = 4 };
  * violated), by obj_improve.  Its merged per-shard heads give the global position at which
  * the reference's scan stops.  n_total / counters[0] = size of the class. */
 enum { SDPCUT_PART_STRONG = 104 };
+/* The other regime of the combined scan over shards: fewer than sel_size strong candidates exist OVERALL, so the scan
+ * visits every entry (cut_select_qp.py:606-623) and each shard's own combined ranking is a sub-list of the global one.
+ * sdpcut_shard_head_device with this value packs the shard's head by (new score, obj_improve, id) with obj_improve as a
+ * third field of the record (the merge's secondary key: the second stable sort of :625 keeps the order of the first, :601). */
+enum { SDPCUT_PART_COMBALL = 105 };
 
 /* kernel variants for sdpcut_set_option(SDPCUT_OPT_KERNEL, ...) */
 enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 };
@@ -164,6 +169,11 @@ int sdpcut_get_candidates(sdpcut_handle h, int64_t count, const int64_t *idx, in
 
 /* LP point vars_values = [X packed (L) | x (n)]  (cut_select_qp.py:137, 200, 547). */
 int sdpcut_set_point(sdpcut_handle h, const double *vars_values);
+/* The handle's pinned, device-mapped staging block for the LP point: *buf = (L + n) doubles the caller may fill IN PLACE
+ * (let the LP solver write its solution there) and then pass to sdpcut_set_point / sdpcut_round_view / sdpcut_round_csr,
+ * which recognise the pointer and skip their host copy (4 MB at n = 1000: ~110 us per round).  Valid until the next
+ * sdpcut_set_instance; write to it only between rounds (a round's completion means its point has left the host). */
+int sdpcut_point_buffer(sdpcut_handle h, double **buf);
 /* same, from a device buffer (async copy on the handle's stream) */
 int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values);
 
@@ -311,23 +321,29 @@ int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int6
  * halves around the single all-gather the caller performs (torch.distributed / RCCL).
  *
  * sdpcut_shard_head_device: enqueue, WITHOUT host synchronisation, this shard's head of the
- * ranking (strat 1, 2 or SDPCUT_PART_STRONG) into one packed device record of 8 + 2*count
- * int64 words
+ * ranking (strat 1, 2, SDPCUT_PART_STRONG or SDPCUT_PART_COMBALL) into one packed device record of
+ * 8 + fields * count int64 words (fields = 3 for SDPCUT_PART_COMBALL, else 2)
  *     [list length, nb_violated, nb_positive, entries written, void flag, 0, 0, 0 |
- *      count scores (fp64 bits) | count GLOBAL ids]
- * padded with (-inf, INT64_MAX); 1 <= count <= 8192.  Measures the strategy needs and sdpcut_score has
+ *      count scores (fp64 bits) | count GLOBAL ids | (fields = 3) count secondary keys = obj_improve (fp64 bits)]
+ * padded with (-inf, INT64_MAX, -inf); 1 <= count <= 16384.  Measures the strategy needs and sdpcut_score has
  * not computed since the last sdpcut_set_point are scored by this call (a sharded round is set_point,
  * shard_head, all-gather, shard_finish); when none of them has been, the score kernels also prepare the
  * selection's first radix digit (SDPCUT_OPT_FUSE_KEYS).
  *
- * sdpcut_shard_finish_round: d_allrec holds the `world` records in rank order.  Merges them
- * by (score descending, id ascending) -- the order of the reference's stable sort on one list
- * (cut_select_qp.py:601, :653) --, keeps the first sel_size entries and produces the eigen-cut
- * rows of those that belong to THIS shard (the others: ks = 0, lam_min = NaN); one transfer,
- * one synchronisation.  headers_out [world][8] are the record headers (the caller sums them);
- * entries beyond the summed list length are pads.  Other outputs as in sdpcut_select_round.
+ * sdpcut_shard_finish_enqueue / sdpcut_shard_finish_wait: d_allrec holds the `world` records in rank order
+ * (`fields` as above).  Enqueue merges them by (score descending, [secondary descending,] id ascending) -- the order
+ * of the reference's stable sorts on one list (cut_select_qp.py:601, :625, :653) --, keeps the first sel_size entries
+ * and produces the eigen-cut rows of those that belong to THIS shard (the others: ks = 0, lam_min = NaN), all stored
+ * by the device into the handle's pinned block; wait returns the block (layout below) once it is complete -- the
+ * round's only host synchronisation.  Several handles may have their halves enqueued before the first wait.
+ * sdpcut_shard_finish_round*: the two calls in one, fields = 2.  headers [world][8] are the record headers (the
+ * caller sums them); entries beyond the summed list length are pads.
  */
 int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t count, void *d_record);
+int sdpcut_shard_finish_enqueue(sdpcut_handle h, int32_t world, int64_t count, int32_t fields, const void *d_allrec,
+                                int64_t sel_size, int32_t coef_ld);
+/* compact_own != 0: block as sdpcut_shard_finish_round_own, *n_own = rows of this shard; 0: as sdpcut_shard_finish_round_view */
+int sdpcut_shard_finish_wait(sdpcut_handle h, int32_t compact_own, const void **block, int64_t *n_own);
 int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count,
                               const void *d_allrec, int64_t sel_size, int32_t coef_ld,
                               int64_t *headers_out, int64_t *idx_out, double *score_out,

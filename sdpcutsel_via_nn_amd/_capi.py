@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("SDPCUT_LIB") or os.path.join(HERE, "libsdpcut_hip.so"
 EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
 PART_STRONG = 104
+PART_COMBALL = 105
 KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
 OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL, OPT_COOP_LAUNCH, OPT_EIG_KERNEL = 1, 2, 3, 4, 5, 6, 7
 STAT_ROUNDS, STAT_SELECT_FALLBACKS, STAT_SCORED = 1, 2, 3
@@ -53,6 +54,7 @@ SIGNATURES = {
     "sdpcut_get_candidates": [_vp, _c.c_int64, _i64p, _i32p, _i32p],
     "sdpcut_set_builtin_networks": [_vp, _c.c_int],
     "sdpcut_set_point": [_vp, _dp],
+    "sdpcut_point_buffer": [_vp, _c.POINTER(_dp)],
     "sdpcut_set_point_device": [_vp, _vp],
     "sdpcut_score": [_vp, _c.c_uint32],
     "sdpcut_get_scores": [_vp, _dp, _dp],
@@ -67,6 +69,8 @@ SIGNATURES = {
     "sdpcut_round_view": [_vp, _dp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_round_csr": [_vp, _dp, _c.c_int, _c.c_int64, _c.POINTER(RoundCsr)],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
+    "sdpcut_shard_finish_enqueue": [_vp, _c.c_int32, _c.c_int64, _c.c_int32, _vp, _c.c_int64, _c.c_int32],
+    "sdpcut_shard_finish_wait": [_vp, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
     "sdpcut_shard_finish_round_own": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p],
@@ -266,6 +270,16 @@ class Scorer(object):
             raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
         self._check(self._lib.sdpcut_set_point(self._h, _ptr(vv, _dp)))
 
+    def point_buffer(self):
+        """The handle's pinned staging block for the LP point as a numpy array of n(n+1)/2 + n doubles: fill it in place
+        and pass IT to set_point / select_round / round_csr -- the library then skips its host copy of the point."""
+        p = _dp()
+        self._check(self._lib.sdpcut_point_buffer(self._h, ctypes.byref(p)))
+        n = self.nb_vars
+        count = n * (n + 1) // 2 + n
+        addr = ctypes.cast(p, _vp).value
+        return np.frombuffer((_c.c_double * count).from_address(addr), dtype=np.float64, count=count)
+
     def set_point_device(self, dev_ptr):
         self._check(self._lib.sdpcut_set_point_device(self._h, _vp(dev_ptr)))
 
@@ -453,6 +467,28 @@ class Scorer(object):
             self._shard_views_cache = dict(headers=hdr, idx=idx, score=sc, lam=lam, coef=coef, rhs=rhs, ks=ks, pos=pos)
             self._shard_view_key = key
         return self._shard_views_cache
+
+    def shard_finish_enqueue(self, world, count, d_allrec_ptr, sel_size, fields=2):
+        """second half of a sharded round, enqueued without host synchronisation (sdpcut_shard_finish_enqueue);
+        fields = 3: the records carry obj_improve as secondary key (SDPCUT_PART_COMBALL)"""
+        self.round_count += 1
+        self._shard_pending = (int(world), int(sel_size), self.row_len)
+        self._check(self._lib.sdpcut_shard_finish_enqueue(self._h, int(world), int(count), int(fields), _vp(d_allrec_ptr),
+                                                          int(sel_size), self.row_len))
+
+    def shard_finish_wait(self, own=True):
+        """-> dict(headers, idx, score, lam, coef, rhs, ks[, pos, n_own]): views of the handle's pinned block, which the
+        device wrote (valid until the next round on this Scorer); own=True: lam / coef / rhs / ks hold only this shard's
+        n_own rows, compacted in head order, pos[:n_own] their positions in the head"""
+        w, m, ld = self._shard_pending
+        block, n_own = _c.c_void_p(), _c.c_int64(0)
+        self._check(self._lib.sdpcut_shard_finish_wait(self._h, 1 if own else 0, ctypes.byref(block), ctypes.byref(n_own)))
+        out = dict(self._shard_views(block.value, w, m, ld))
+        if own:
+            out["n_own"] = int(n_own.value)
+        else:
+            out.pop("pos")
+        return out
 
     def shard_finish_round(self, world, count, d_allrec_ptr, sel_size, copy=False):
         """merge the gathered records, cut rows of this shard's entries

@@ -490,6 +490,32 @@ int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, i
     return SDPCUT_OK;
 }
 
+static int ensure_point_stage(sdpcut_ctx *h)
+{
+    const size_t bytes = (size_t)(h->L + h->nb_vars) * sizeof(double);
+    if (h->point_stage_bytes >= bytes) return 0;
+    HIP_TRY(h, sdpcut_sync(h));
+    if (h->point_stage) (void)hipHostFree(h->point_stage);
+    h->point_stage = nullptr;
+    h->point_stage_bytes = 0;
+    HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocMapped));
+    HIP_TRY(h, hipHostGetDevicePointer(&h->point_stage_dev, h->point_stage, 0));
+    h->point_stage_bytes = bytes;
+    return 0;
+}
+
+int sdpcut_point_buffer(sdpcut_handle h, double **buf)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!buf) return sdpcut_fail(h, SDPCUT_EINVAL, "buf is NULL");
+    if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_point_stage(h);
+    if (rc) return rc;
+    *buf = (double *)h->point_stage;
+    return SDPCUT_OK;
+}
+
 int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
 {
     if (!h) return SDPCUT_EINVAL;
@@ -500,24 +526,20 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
     // call returns as soon as the host copy is done -- the caller may reuse its buffer at once -- and
     // the DMA runs behind it on the stream, in front of the score kernels (no blocking round trip
     // per round).  The staging block is reused once the previous transfer out of it has completed.
+    // A caller that wrote the point straight into the staging block (sdpcut_point_buffer) skips the copy.
     const size_t bytes = (size_t)(h->L + h->nb_vars) * sizeof(double);
-    if (h->point_stage_bytes < bytes) {
-        HIP_TRY(h, sdpcut_sync(h));
-        if (h->point_stage) (void)hipHostFree(h->point_stage);
-        h->point_stage = nullptr;
-        h->point_stage_bytes = 0;
-        HIP_TRY(h, hipHostMalloc(&h->point_stage, bytes, hipHostMallocMapped));
-        HIP_TRY(h, hipHostGetDevicePointer(&h->point_stage_dev, h->point_stage, 0));
-        h->point_stage_bytes = bytes;
+    int rc = ensure_point_stage(h);
+    if (rc) return rc;
+    if (vars_values != (const double *)h->point_stage) {
+        // (every round ends in a host wait on the device, so this one is normally skipped; an event per
+        // transfer would put a barrier packet -- ~10 us -- in front of every score launch)
+        if (h->point_inflight) HIP_TRY(h, sdpcut_sync(h));
+        std::memcpy(h->point_stage, vars_values, bytes);
     }
-    // (every round ends in a host wait on the device, so this one is normally skipped; an event per
-    // transfer would put a barrier packet -- ~10 us -- in front of every score launch)
-    if (h->point_inflight) HIP_TRY(h, sdpcut_sync(h));
-    std::memcpy(h->point_stage, vars_values, bytes);
     // a kernel of the compute queue pulls the block over PCIe (mapped host memory): the score launch
     // follows it in queue order, whereas a copy-engine transfer costs a cross-queue hand-off (~10 us)
     // in front of every round
-    int rc = launch_point_copy(h, (const double *)h->point_stage_dev, h->L + h->nb_vars);
+    rc = launch_point_copy(h, (const double *)h->point_stage_dev, h->L + h->nb_vars);
     if (rc) return rc;
     h->point_inflight = true;
     h->have_point = true;

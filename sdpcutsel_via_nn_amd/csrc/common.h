@@ -100,6 +100,7 @@ struct sdpcut_ctx {
     size_t tmp_bytes = 0;
     // top-k select workspace (topk.hip)
     void *d_topk_ws = nullptr;
+    int64_t tk_coresident = 256;   // workgroups of tk_refine_kernel resident at once (occupancy x CUs), set with the workspace
     void *d_topk_ws_alt = nullptr; // second workspace: zeroed by the epilogue of a round for the next one
     bool topk_alt_clean = false;   // d_topk_ws_alt has been (stream-ordered) zeroed and may be swapped in
     uint64_t *d_sel_key = nullptr;
@@ -122,6 +123,9 @@ struct sdpcut_ctx {
     bool point_inflight = false;   // a transfer out of point_stage may still be running
     int64_t round_serial = 0;      // completion word of the fused round (round_rows_kernel -> pinned header)
     uint32_t *d_done_ticket = nullptr;
+    // sdpcut_shard_finish_enqueue -> sdpcut_shard_finish_wait
+    int64_t shard_pending_serial = 0, shard_pending_sel = 0;
+    int32_t shard_pending_world = 0, shard_pending_ld = 0;
 };
 
 // every host wait on the handle's stream goes through here: it also tells sdpcut_set_point that the

@@ -87,10 +87,10 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
         if ((threadIdx.x & 63) == 0 && c_viol) atomicAdd(&tk_cnt, c_viol);
         __syncthreads();
         if (threadIdx.x == 0 && tk_cnt)
-            __hip_atomic_fetch_add((unsigned long long *)&A.tk->counters[1], (unsigned long long)tk_cnt, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add((unsigned long long *)&A.tk->viol_rep[blockIdx.x % TK_SHREP], (unsigned long long)tk_cnt, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         if (tk_hist[threadIdx.x])
-            __hip_atomic_fetch_add(&A.tk->hist[0][blockIdx.x % TK_HREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -177,7 +177,7 @@ int rank_fast_mode(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
     if (sel_size > n) sel_size = n;
     if (score_add) *score_add = 0.0;
     if (!(n > 0 && max_out >= 1 && max_out <= 16384)) return 0;      // TK_MAXK (topk_dev.h)
-    if (max_out > 8192 && (strat == SDPCUT_STRAT_COMB || h->shard_rec)) return 0;     // big heads: plain rankings only
+    if (max_out > 8192 && strat == SDPCUT_STRAT_COMB) return 0;     // big heads: plain rankings only (the device-resolved regime's sort keeps keys AND indices in LDS)
     if (strat == SDPCUT_STRAT_FEAS) return 1;
     if (strat == SDPCUT_STRAT_OPT) return 2;
     if (strat == SDPCUT_PART_STRONG) return 3;

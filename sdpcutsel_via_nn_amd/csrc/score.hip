@@ -279,6 +279,25 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
     out1[0] = (q < NT) ? t1 : 0.0;
 }
 
+// The same for a pass of ONE column tile (the three-waves-per-SIMD variant of the kernel): lanes q < NT evaluate the tansig
+// of neuron u = q, the other k-slot lanes idle through it.
+template <int NT, bool CLAMP = true>
+__device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], const double *bias, int q, d4 &out0)
+{
+    static_assert(NT <= 2, "at most two tail neurons");
+    double pre = 0.0;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        double v = ts[0][u];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        pre = (q == u) ? v + bias[u] : pre;
+    }
+    const double t = tansig_y8<CLAMP>(pre);
+    out0 = d4{0.0, 0.0, 0.0, 0.0};
+    out0[0] = (q < NT) ? t : 0.0;
+}
+
 // Timing experiments (tools/build_ablation.sh; results are wrong by design): drop the bias or
 // weight-fragment loads to see what their latency costs.
 // Biases, tail-row weights and output weights (<= 8.5 KB) are copied to LDS once per workgroup:
@@ -351,8 +370,31 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 // also count the class members by the leading radix digit of that mode's selection keys (ScoreArgs::tk).
 // CLAMP = false (NetDev::unclamped_ok): the tansig clamps are dropped and the staged inputs are
 // clamped to [-3, 3] instead (inactive for every x in [0, 1], |q| <= 1/k, see sdpcut_set_network).
-template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true>
-__global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
+// J = 16-candidate column tiles per pass.  2 (default): every weight fragment feeds two MFMAs, ~230 registers, two waves
+// per SIMD.  1: half the accumulator state (<= 168 registers: three waves per SIMD), twice the fragment loads and tail
+// evaluations per candidate -- the experiment of VERDICT r2 item 4, measured in DESIGN.md section 5.
+#ifndef SDPCUT_MFMA_J
+#define SDPCUT_MFMA_J 2
+#endif
+#ifndef SDPCUT_MFMA_J_K2
+#define SDPCUT_MFMA_J_K2 SDPCUT_MFMA_J
+#endif
+#ifndef SDPCUT_MFMA_J_K3
+#define SDPCUT_MFMA_J_K3 SDPCUT_MFMA_J
+#endif
+#ifndef SDPCUT_MFMA_J_K4
+#define SDPCUT_MFMA_J_K4 SDPCUT_MFMA_J
+#endif
+#ifndef SDPCUT_MFMA_J_K5
+#define SDPCUT_MFMA_J_K5 SDPCUT_MFMA_J
+#endif
+#ifndef SDPCUT_MFMA_J1_WAVES
+#define SDPCUT_MFMA_J1_WAVES 3
+#endif
+constexpr int mfma_cols(int K) { return K == 2 ? SDPCUT_MFMA_J_K2 : K == 3 ? SDPCUT_MFMA_J_K3 : K == 4 ? SDPCUT_MFMA_J_K4 : SDPCUT_MFMA_J_K5; }
+
+template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true, int J = 2>
+__global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void score_mfma_kernel(ScoreArgs A)
 {
     constexpr int M = K * (K + 1) / 2;
     constexpr int DIN = K + M;
@@ -363,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
     // per k-step for 1/8 of the work: those rows run on the VALU instead (tail_rows below).
     constexpr int NT = (H - 16 * (T - 1) <= 4) ? H - 16 * (T - 1) : 0;
     constexpr int TM = NT ? T - 1 : T;     // row tiles computed with MFMA
-    constexpr int J = 2;                   // 16-candidate column tiles per pass
-    constexpr int NPASS = 64 / (16 * J);
+    constexpr int NPASS = 64 / (16 * J);   // passes of J 16-candidate column tiles over the wave's strip
+    static_assert(J == 1 || J == 2, "one or two column tiles per pass");
     static_assert(T == 4, "hidden width must be in 49..64");
 
     __shared__ double feat[4][S0 * 4][64];  // per wave: feature-major strip of 64 candidates
@@ -496,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
             for (int s = 0; s < S0; ++s)
 #pragma unroll
-                for (int j = 0; j < J; ++j) bin[s][j] = feat[wave][4 * s + q][32 * pass + 16 * j + c16];
+                for (int j = 0; j < J; ++j) bin[s][j] = feat[wave][4 * s + q][16 * J * pass + 16 * j + c16];
 
             d4 prev[T][J], cur[T][J];
             const double *wf = net.wfrag;
@@ -548,7 +590,8 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                         for (int j = 0; j < J; ++j) ts[j][u] = fma(bin[s][j], w, ts[j][u]);
                     }
-                tail_rows2<NT, CLAMP>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                if constexpr (J == 2) tail_rows2<NT, CLAMP>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][J - 1]);
+                else tail_rows1<NT, CLAMP>(ts, BIAS_PTR + 16 * (T - 1), q, cur[T - 1][0]);
             }
             wf += T * S0 * 64;
             // ---------------- hidden -> hidden layers (rolled: bounds code size and live ranges)
@@ -614,7 +657,8 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
 #pragma unroll
                             for (int j = 0; j < J; ++j) ts[j][u] = fma(prev[s / 4][j][s % 4], w, ts[j][u]);
                         }
-                    tail_rows2<NT, CLAMP>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][1]);
+                    if constexpr (J == 2) tail_rows2<NT, CLAMP>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0], cur[T - 1][J - 1]);
+                    else tail_rows1<NT, CLAMP>(ts, BIAS_PTR + l * 64 + 16 * (T - 1), q, cur[T - 1][0]);
                 }
                 wf += T * SH * 64;
             }
@@ -630,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
                         if (16 * t + 4 * r < H) part = fma(cur[t][j][r], WOUT_AT(16 * t + 4 * r + q), part);
                 part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
-                if (q == 0) ynn[wave][32 * pass + 16 * j + c16] = part;
+                if (q == 0) ynn[wave][16 * J * pass + 16 * j + c16] = part;
             }
         }
         wave_lds_sync();
@@ -682,10 +726,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(ScoreArgs A)
         }
         __syncthreads();
         if (threadIdx.x < 2 && tk_cnt[threadIdx.x])
-            __hip_atomic_fetch_add((unsigned long long *)&A.tk->counters[1 + threadIdx.x], (unsigned long long)tk_cnt[threadIdx.x],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add((unsigned long long *)(threadIdx.x ? &A.tk->pos_rep[blockIdx.x % TK_SHREP] : &A.tk->viol_rep[blockIdx.x % TK_SHREP]),
+                                   (unsigned long long)tk_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tk_hist[threadIdx.x])
-            __hip_atomic_fetch_add(&A.tk->hist[0][blockIdx.x % TK_HREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1041,10 +1085,10 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
-        if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, F, C>), grid, 256);          \
-        if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, F, C>), grid, 256);          \
-        if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, F, C>), grid, 256);          \
-        if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, F, C>), grid, 256);          \
+        if (K == 2) SCORE_LAUNCH((score_mfma_kernel<2, 64, 3, F, C, mfma_cols(2)>), grid, 256);          \
+        if (K == 3) SCORE_LAUNCH((score_mfma_kernel<3, 50, 3, F, C, mfma_cols(3)>), grid, 256);          \
+        if (K == 4) SCORE_LAUNCH((score_mfma_kernel<4, 50, 3, F, C, mfma_cols(4)>), grid, 256);          \
+        if (K == 5) SCORE_LAUNCH((score_mfma_kernel<5, 64, 4, F, C, mfma_cols(5)>), grid, 256);          \
     } while (0)
         const int f = A.tk ? A.tk_mode : 0;
         if (f != 0 && f != TK_MODE_FEAS && f != TK_MODE_OPT && f != TK_MODE_STRONG)

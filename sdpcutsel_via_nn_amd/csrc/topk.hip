@@ -111,72 +111,14 @@ __global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(int p, int64_t n, i
     finish_pass(ws, p, k, hist, gridDim.x);
 }
 
-// Passes p0..7 in ONE launch.  Normally the selection was closed after one or two digits and every
-// block returns at once (one empty launch instead of six).  Otherwise (masses of equal keys) the
-// blocks run the remaining passes separated by a grid barrier: the block that resolves digit p
-// publishes ready[p+1], the others wait for it.  All TK_MAXBLK (= 256) blocks of 256 threads are
-// resident together on the 256 CUs, and the wait is bounded anyway: when the flag does not come
-// (the GPU shared with a kernel that keeps blocks of this grid from starting) counters[4] is raised,
-// every block leaves, and the host falls back to the full-sort path.
-#define TK_SPIN_LIMIT (1 << 16)      // x s_sleep: a few milliseconds; a legitimate wait is tens of microseconds
-__global__ __launch_bounds__(TK_THREADS) void tk_hist_rest_kernel(int p0, int64_t n, int64_t k, const uint64_t *keys,
-                                                                  TopkWs *ws)
-{
-    __shared__ uint32_t hist[256];
-    __shared__ int go;
-    for (int p = p0; p < 8; ++p) {
-        if (p > p0) {
-            if (threadIdx.x == 0) {
-                int ok = 1;
-                uint32_t it = 0;
-                while (__hip_atomic_load(&ws->ready[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
-                        st_i64(&ws->counters[4], 1);
-                        ok = 0;
-                        break;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                go = ok;
-            }
-            __syncthreads();
-            if (!go) return;
-        }
-        TkState st;
-        st.prefix = (uint64_t)ld_i64((const int64_t *)&ws->state[p].prefix);
-        st.need = ld_i64(&ws->state[p].need);
-        st.stop = ld_i64(&ws->state[p].stop);
-        if (st.stop || st.need < 1) return;               // uniform over the grid
-        hist[threadIdx.x] = 0;
-        __syncthreads();
-        const int shift = 8 * (7 - p);
-        const int64_t stride = (int64_t)gridDim.x * TK_THREADS;
-        const int64_t rounds = (n + stride - 1) / stride;
-        for (int64_t r0 = 0; r0 < rounds; r0 += TK_UNROLL) {
-            uint64_t key[TK_UNROLL];
-            bool in[TK_UNROLL];
-#pragma unroll
-            for (int u = 0; u < TK_UNROLL; ++u) {
-                const int64_t i = (r0 + u) * stride + (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-                in[u] = i < n;
-                key[u] = in[u] ? keys[i] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < TK_UNROLL; ++u) {
-                const bool match = in[u] && (((key[u] ^ st.prefix) >> (shift + 8)) == 0);
-                hist_add(hist, (uint32_t)((key[u] >> shift) & 255), match);
-            }
-        }
-        __syncthreads();
-        finish_pass(ws, p, k, hist, gridDim.x, true);
-        __syncthreads();
-    }
-}
+// bounded waits of the fused selection kernel (tk_refine_kernel): x s_sleep, a few milliseconds; a legitimate wait is
+// tens of microseconds.  When a flag does not come (the GPU shared with a kernel that keeps workgroups of the grid from
+// starting) counters[4] is raised, every workgroup leaves, and the host answers through a path without waits.
+#define TK_SPIN_LIMIT (1 << 16)
 
 // One-shot grid barrier `b` of a selection (its arrival counter starts at zero with the workspace).
 // Every thread's device-scope atomics are drained before the workgroup arrives.  Bounded like the
-// wait of tk_hist_rest_kernel: if the other workgroups do not show up (the GPU shared with a kernel
+// wait for a published state: if the other workgroups do not show up (the GPU shared with a kernel
 // that keeps them from starting) counters[4] marks the selection void and everybody leaves.
 static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 {
@@ -202,14 +144,14 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 }
 
 // Passes 1..7, the count and the compaction in ONE launch (the fast path's replacement of
-// tk_hist_kernel + tk_hist_rest_kernel + tk_count_kernel + tk_write_kernel: three launch hand-offs
+// tk_hist_kernel (x7) + tk_count_kernel + tk_write_kernel: launch hand-offs
 // of ~5 us each become one or two grid barriers).  After pass 1 the selection is normally closed
 // (early stop: every key >= T, at most TK_MAXK of them, in any order -- the sort that follows orders
 // them): each workgroup counts its keys >= T, reserves its slice of the output with ONE fetch-add and
 // writes.  Masses of equal keys run the remaining digits behind grid barriers and cut the last group by
 // index, which needs the per-workgroup counts of all workgroups: one more barrier.
 //
-// ONFLY: the score kernels have already counted the leading digit (ScoreArgs::tk -> TopkWs::hist[0]) and
+// ONFLY: the score kernels have already counted the leading digit (ScoreArgs::tk -> TopkWs::hist_score) and
 // there is no key array: every workgroup resolves pass 0 for itself (same inputs, same result), and the
 // keys are built from the scores as they are read -- once, into the LDS cache, when the chunk fits.
 // Mode COMBAUTO resolved to COMBALL (fewer strong candidates than asked for -- the score kernels
@@ -256,9 +198,14 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
 #pragma unroll
         for (int r = 0; r < TK_SREP; ++r) strong += ws->strong_rep[r];
         if (both) mode = strong >= sel ? TK_MODE_STRONG : TK_MODE_COMBALL;      // uniform over the grid
+        int64_t nviol = 0, npos = 0;      // counted by the score / eigenvalue kernels, replicated by workgroup
+#pragma unroll 4
+        for (int r = 0; r < TK_SHREP; ++r) { nviol += ws->viol_rep[r]; npos += ws->pos_rep[r]; }
         const int64_t cls = (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? n
-                            : (mode == TK_MODE_FEAS) ? ws->counters[1] : strong;
+                            : (mode == TK_MODE_FEAS) ? nviol : strong;
         if (threadIdx.x == 0 && blockIdx.x == 0) {
+            st_i64(&ws->counters[1], nviol);
+            st_i64(&ws->counters[2], npos);
             st_i64(&ws->mode, mode);
             st_i64(&ws->counters[6], mode);
             st_i64(&ws->counters[5], strong);      // for the host (round header)
@@ -268,7 +215,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             p_first = 0;
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
-            resolve_digit(ws, 0, k, ws->hist[0], cls, &st1, blockIdx.x == 0, mode, true);
+            resolve_digit(ws, 0, k, ws->hist_score, cls, &st1, blockIdx.x == 0, mode, true, TK_SHREP);
         }
         __syncthreads();
     }
@@ -772,9 +719,20 @@ template <bool TIE>
 __global__ __launch_bounds__(TK_THREADS) void tk_mergerank_big_kernel(int64_t base, double score_add, const TopkWs *ws,
                                                                       const uint64_t *tile_key, const uint32_t *tile_idx,
                                                                       int64_t *idx_out, double *score_out, const double *obj,
-                                                                      int raw, int64_t emit_limit)
+                                                                      int raw, int64_t emit_limit, int64_t *rec_hdr,
+                                                                      int64_t rec_count, int64_t rec_len)
 {
     __shared__ uint64_t sk[TK_MAXK];
+    if (rec_hdr) {      // shard record: header and padding, as in tk_mergerank_kernel
+        const int64_t g = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+        const int64_t written = ws->counters[4] ? 0 : ws->counters[3];
+        if (g < rec_count && g >= written) {
+            score_out[g] = -__builtin_huge_val();
+            idx_out[g] = 0x7fffffffffffffffLL;
+        }
+        if (g < 8)
+            rec_hdr[g] = g == 0 ? (rec_len >= 0 ? rec_len : ws->counters[0]) : g <= 4 ? ws->counters[g] : 0;
+    }
     const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
     if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
     const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
@@ -838,6 +796,12 @@ int ensure_topk_ws(sdpcut_ctx *h)
     // first half: compacted selection, second half: the sorted tiles
     HIP_TRY(h, hipMalloc((void **)&h->d_sel_key, 2 * TK_MAXK * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc((void **)&h->d_sel_idx, 2 * TK_MAXK * sizeof(uint32_t)));
+    // workgroups of the fused selection kernel the device holds at once (its grid barriers rely on it)
+    int b_on = 0, b_off = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_on, tk_refine_kernel<true>, TK_THREADS, 0));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_off, tk_refine_kernel<false>, TK_THREADS, 0));
+    h->tk_coresident = (int64_t)(b_on < b_off ? b_on : b_off) * h->n_cu;
+    if (h->tk_coresident < 1) h->fused_tail = false;      // (never on gfx950: 4 per CU by LDS) the launch-per-digit path has no waits
     return 0;
 }
 
@@ -947,15 +911,17 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
                                     const double *eig = nullptr, const double *obj = nullptr)
 {
     if (onfly && (compacted || !h->fused_tail)) return sdpcut_fail(h, SDPCUT_ESTATE, "top-k select: no key pass to continue from");
-    int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
-    const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
+    // Workgroups of the passes: one LDS-cached chunk of TK_CACHE keys each, as many as can be RESIDENT together -- the
+    // fused kernel's grid barriers (masses of equal keys only) need that, and its waits are bounded anyway.  A fixed
+    // grid of 256 read the 200 MB of a 1.25e7-candidate shard at 18 % of the HBM rate: the loads in
+    // flight, not the bandwidth, were the limit.
+    const int64_t want = (n + TK_CACHE - 1) / TK_CACHE;
+    const int64_t cap = h->fused_tail ? (h->tk_coresident < TK_MAXBLK ? h->tk_coresident : TK_MAXBLK) : TK_MAXBLK;
+    const int grid = (int)(want < 1 ? 1 : (want < cap ? want : cap));
     if (!compacted) {
         int64_t chunk = (n + grid - 1) / grid;
         chunk = (chunk + TK_THREADS - 1) / TK_THREADS * TK_THREADS;
         if (h->fused_tail) {
-            // cooperative launch: the runtime guarantees that all workgroups of the grid are resident
-            // together, which is what the kernel's grid barriers need (256 workgroups of 256 threads on
-            // 256 CUs); its waits stay bounded anyway
             const uint64_t *keys_arg = h->d_key_a;
             uint64_t *sk_arg = h->d_sel_key;
             uint32_t *si_arg = h->d_sel_idx;
@@ -965,14 +931,16 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             if (onfly)      // (a measure the mode does not use is never looked at: any readable array of n doubles will do)
                 hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, nullptr, ws,
                                    h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig);
-            else if (h->coop_launch)
+            else if (h->coop_launch)      // the runtime guarantees the co-residency (+20 us per launch)
                 HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else
                 hipLaunchKernelGGL(tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
                                    h->d_sel_key, h->d_sel_idx, mode, sel, eig, obj);
         } else {
-            hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 1, n, k, h->d_key_a, ws);
-            hipLaunchKernelGGL(tk_hist_rest_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, 2, n, k, h->d_key_a, ws);
+            // one launch per digit, no wait anywhere inside a kernel: the path that always answers (each launch returns at
+            // once when the selection has been closed by an earlier digit)
+            for (int p = 1; p < 8; ++p)
+                hipLaunchKernelGGL(tk_hist_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, p, n, k, h->d_key_a, ws);
             hipLaunchKernelGGL(tk_count_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws);
             hipLaunchKernelGGL(tk_write_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, chunk, h->d_key_a, ws,
                                h->d_sel_key, h->d_sel_idx);
@@ -986,15 +954,15 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
     const dim3 g_sort(ntiles), g_merge(ntiles * TK_TILE / TK_THREADS), blk(TK_THREADS);
     if (maxk > TK_LDSK) {
         // big heads (8193 .. 16384): keys-only merge; the device-resolved regime never asks for them
-        if (mode == TK_MODE_COMBAUTO || h->shard_rec) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: head too long for this mode");
+        if (mode == TK_MODE_COMBAUTO) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: head too long for this mode");
         if (tie_obj) {
             hipLaunchKernelGGL(tk_tilesort_kernel<1>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key, tile_idx, tie_obj);
             hipLaunchKernelGGL(tk_mergerank_big_kernel<true>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,
-                               d_idx_out, d_score_out, tie_obj, raw, emit_limit);
+                               d_idx_out, d_score_out, tie_obj, raw, emit_limit, h->shard_rec, h->shard_rec_count, h->shard_rec_len);
         } else {
             hipLaunchKernelGGL(tk_tilesort_kernel<0>, g_sort, blk, 0, h->stream, ws, h->d_sel_key, h->d_sel_idx, tile_key, tile_idx, tie_obj);
             hipLaunchKernelGGL(tk_mergerank_big_kernel<false>, g_merge, blk, 0, h->stream, base, score_add, ws, tile_key, tile_idx,
-                               d_idx_out, d_score_out, tie_obj, raw, emit_limit);
+                               d_idx_out, d_score_out, tie_obj, raw, emit_limit, h->shard_rec, h->shard_rec_count, h->shard_rec_len);
         }
     } else {
         if (raw) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: raw output needs the big-head merge");

@@ -8,7 +8,7 @@
 #include "keys.h"
 
 #define TK_THREADS 256
-#define TK_MAXBLK 256
+#define TK_MAXBLK 1024   // most workgroups a selection pass is launched with (blk_eq / blk_gt slots)
 #define TK_LDSK 8192     // heads whose compacted superset (keys AND indices) fits the merge kernel's LDS
 #define TK_MAXK 16384    // largest head: the merge keeps the keys in LDS and reads indices only on ties
 #define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
@@ -19,6 +19,10 @@
 #define TK_HREP 8
 #endif
 #define TK_SREP 8
+// Replicas of the leading-digit histogram the SCORE kernels flush into (TopkWs::hist_score): thousands of workgroups add
+// their handful of non-empty bins when they retire; with 8 replicas the eigenvalue kernel's 3907 workgroups queued ~500
+// deep on every cell (+11 us on a 48 us kernel), with 32 the chains are ~120 deep and hidden behind the kernel's tail.
+#define TK_SHREP 32
 
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
@@ -38,7 +42,7 @@ struct TkState {
 struct TopkWs {
     uint32_t hist[8][TK_HREP][256];   // [pass 0..7 = digit 7..0][replica][bin]
     int64_t counters[8];     // [0] class size  [1] nb_violated  [2] nb_positive  [3] k_eff
-                             // [4] != 0: tk_hist_rest_kernel gave up waiting, the selection is void
+                             // [4] != 0: a bounded wait of tk_refine_kernel expired, the selection is void
                              // [5] strong candidates counted by the score kernels (TK_MODE_COMBAUTO)
                              // [6] mode the selection ran in (copy of `mode` for the host)
     TkState state[9];        // state[p]: after p digits
@@ -47,13 +51,17 @@ struct TopkWs {
     uint32_t blk_gt[TK_MAXBLK];
     int64_t n_sel;           // entries compacted by tk_write_kernel (>= k_eff after an early stop)
     int64_t mode;            // TK_MODE_* of the running selection (written by its pass 0)
-    uint32_t ready[9];       // tk_hist_rest_kernel: state[p] has been published inside the launch
+    uint32_t ready[9];       // tk_refine_kernel: state[p] has been published inside the launch
     uint32_t pad_[1];
     int64_t strong_rep[TK_SREP];   // strong candidates counted by the score kernels, replicated by workgroup
                                    // (same-address device atomics are serialised, see TK_HREP)
     uint32_t bar[8];               // one-shot grid barriers of the fused kernels (arrival counters)
     uint32_t hist_alt[TK_HREP][256];   // leading-digit histogram of the COMBALL keys when the score kernels counted the
-                                       // STRONG keys into hist[0] and the device resolved the other regime
+                                       // STRONG keys into hist_score and the device resolved the other regime
+    uint32_t hist_score[TK_SHREP][256];   // leading digit of the selection's keys, counted by the score / eigenvalue kernels
+    int64_t viol_rep[TK_SHREP];           // violated / positive candidates counted by the same kernels, replicated by workgroup:
+    int64_t pos_rep[TK_SHREP];            // ONE counter each would queue thousands of retiring workgroups on one address (~15 ns
+                                          // apiece: 58 us for the eigenvalue kernel's 3907 workgroups -- longer than the kernel runs)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -109,7 +117,7 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
 // would queue up on one cache line).
 static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k, const uint32_t (*row)[256] = nullptr,
                                      int64_t cls_known = -1, TkState *mine = nullptr, bool publish = true,
-                                     int mode_known = 0, bool plain = false)
+                                     int mode_known = 0, bool plain = false, int nrep = TK_HREP)
 {
     __shared__ uint32_t suf[TK_THREADS];
     const int t = threadIdx.x;
@@ -127,8 +135,7 @@ static __device__ void resolve_digit(TopkWs *ws, int p, int64_t k, const uint32_
     }
     {
         uint32_t acc = 0;
-#pragma unroll
-        for (int r = 0; r < TK_HREP; ++r) acc += plain ? row[r][t] : ld_u32(&row[r][t]);      // plain: written by an earlier launch
+        for (int r = 0; r < nrep; ++r) acc += plain ? row[r][t] : ld_u32(&row[r][t]);      // plain: written by an earlier launch
         suf[t] = acc;
     }
     {   // suffix sums S[t] = sum_{b >= t} hist[b]: within each wave by shuffles, then the totals of the waves above
@@ -212,7 +219,7 @@ static __device__ void finish_pass(TopkWs *ws, int p, int64_t k, const uint32_t 
         }
         __syncthreads();
         resolve_digit(ws, p, k, row);
-        if (publish) {      // grid barrier of tk_hist_rest_kernel: state[p+1] is complete
+        if (publish) {      // grid barrier of tk_refine_kernel: state[p+1] is complete
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {

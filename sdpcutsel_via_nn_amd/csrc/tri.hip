@@ -91,7 +91,17 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
         if (max_out > 0) {
             rc = topk_select_keys_on_device(h, E, max_out, d_entry_out, d_viol_out, cnt);
             if (rc) return rc;
-            if (cnt[4]) return sdpcut_fail(h, SDPCUT_EHIP, "tri_separate: selection gave up (GPU shared with a blocking kernel)");
+            if (cnt[4]) {
+                // a bounded wait of the fused selection expired (the GPU shared with a kernel that kept its workgroups
+                // from starting): the same selection with one launch per digit has no waits and always answers
+                const bool fused = h->fused_tail;
+                h->fused_tail = false;
+                rc = topk_select_keys_on_device(h, E, max_out, d_entry_out, d_viol_out, cnt);
+                h->fused_tail = fused;
+                ++h->stat_fallbacks;
+                if (rc) return rc;
+                if (cnt[4]) return sdpcut_fail(h, SDPCUT_EHIP, "tri_separate: selection void");
+            }
         } else {
             HIP_TRY(h, hipMemcpyAsync(cnt, h->d_counters, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, sdpcut_sync(h));

@@ -31,13 +31,21 @@ _HEAD = 5000                          # _SDP_CUTS_PER_ROUND_MAX (:37): rank-list
 _FUSED_HEAD_MAX = 16384               # longest head the fused round (sdpcut_round_csr) assembles
 
 
+_SPARSE_PAIR = None
+
+
 def _default_sparse_pair():
-    try:
-        import cplex                      # the reference's LP object, if installed
-        return cplex.SparsePair
-    except ImportError:
-        from .harness import SparsePair
-        return SparsePair
+    """cplex.SparsePair if the reference's LP library is installed, else the stand-alone twin; looked up once
+    (a failing ``import cplex`` walks the whole module path: ~60 us per call, once per round before it was cached)"""
+    global _SPARSE_PAIR
+    if _SPARSE_PAIR is None:
+        try:
+            import cplex                      # the reference's LP object, if installed
+            _SPARSE_PAIR = cplex.SparsePair
+        except ImportError:
+            from .harness import SparsePair
+            _SPARSE_PAIR = SparsePair
+    return _SPARSE_PAIR
 
 
 def rows_to_csr(coef, cols, ks):

@@ -61,23 +61,30 @@ class DeviceOps(object):
                 sec[:w] = tmp_o
         return scores, ids, sec, total, counters
 
-    # -- fused round (sdpcut_shard_head_device / sdpcut_shard_finish_round) ----------------
-    max_head = 8192
+    # -- fused round (sdpcut_shard_head_device / sdpcut_shard_finish_enqueue / _wait) ----------------
+    max_head = 16384
 
     def shard_head(self, strat, count):
-        """packed head record of this shard, enqueued on the current stream (no host sync)"""
-        rec = self._rec.get(count)           # one buffer per head length, reused every round
+        """packed head record of this shard, enqueued on the current stream (no host sync); strat
+        _capi.PART_COMBALL: three fields per entry (new score, id, obj_improve), else two"""
+        fields = 3 if strat == _capi.PART_COMBALL else 2
+        rec = self._rec.get((count, fields))           # one buffer per record shape, reused every round
         if rec is None:
-            rec = self._rec[count] = torch.empty(8 + 2 * count, dtype=torch.int64, device=self.device)
+            rec = self._rec[(count, fields)] = torch.empty(8 + fields * count, dtype=torch.int64, device=self.device)
         self.scorer.shard_head_device(strat, count, rec.data_ptr())
         return rec
 
-    def shard_finish(self, world, count, allrec, sel_size):
-        return self.scorer.shard_finish_round(world, count, allrec.data_ptr(), sel_size)
+    def shard_finish_enqueue(self, world, count, allrec, sel_size, fields=2):
+        """merge of the gathered records + rows of the own entries, enqueued (no host sync)"""
+        self.scorer.shard_finish_enqueue(world, count, allrec.data_ptr(), sel_size, fields)
 
-    def shard_finish_own(self, world, count, allrec, sel_size):
-        """same, the own rows already compacted by the library (no mask arithmetic on the host)"""
-        return self.scorer.shard_finish_round_own(world, count, allrec.data_ptr(), sel_size)
+    def shard_finish_wait(self):
+        """-> dict(headers, idx, score, lam, coef, rhs, ks, pos, n_own): the round's one host wait"""
+        return self.scorer.shard_finish_wait(own=True)
+
+    def shard_finish(self, world, count, allrec, sel_size):
+        """both halves in one call, rows at their head positions (ks = 0 / lam = NaN for other shards' entries)"""
+        return self.scorer.shard_finish_round(world, count, allrec.data_ptr(), sel_size)
 
     def rows_of(self, global_ids):
         """eigen-cut rows of the entries of ``global_ids`` (numpy) that live on this shard
@@ -109,6 +116,8 @@ class ShardedSelector(object):
         self._solo = self.world == 1 and not (dist.is_initialized() and os.environ.get("SDPCUT_FORCE_COLLECTIVES") == "1")
         self.n_local = int(n_local)
         self.n_global = self._sum(self.n_local)
+        # rounds served by: the one-collective route / the every-entry-visited route (two collectives) / the unfused last resort
+        self.path_counts = dict(common=0, comball=0, unfused=0)
 
     # -- collectives ---------------------------------------------------------------------
     def _sum(self, *vals):
@@ -213,7 +222,10 @@ class ShardedSelector(object):
         Common regime (strategies 1 and 2; strategy 4 with at least sel_size strong candidates
         overall): ONE collective and ONE host synchronisation per round -- the shard's head and
         its counters are packed on the device, all-gathered, merged and turned into rows by
-        two library calls (shard_head / shard_finish).  Otherwise :meth:`select` runs.
+        library calls (shard_head / shard_finish_enqueue / shard_finish_wait).  Strategy 4 with fewer
+        strong candidates: every entry is visited by the scan, and a second pass of the same three
+        calls gathers the shards' combined rankings with obj_improve as the merge's secondary key
+        (one more collective, one more wait; no torch glue).
 
         copy=False: ``ids`` / ``scores`` are views of that block as well (no host copies at all on the round's
         critical path; the +BIG_M of the combined strategy is added in place).
@@ -221,40 +233,71 @@ class ShardedSelector(object):
         The shard need not be scored beforehand: shard_head scores what the current point lacks (and,
         when nothing has been scored yet, lets the score kernels prepare the selection's first radix
         digit); :meth:`select` on its own expects the scores (``ops.ensure_scored``)."""
+        return self.end_round(self.begin_round(strat, sel_size), copy=copy)
+
+    def begin_round(self, strat, sel_size):
+        """First part of :meth:`select_round`, up to and including the enqueued merge + rows: no host wait.
+        -> token for :meth:`end_round`.  Two selectors (the two covers of a QCQP round) may both begin before either ends."""
         if strat not in (1, 2, 4):
             raise ValueError("strategy must be 1, 2 or 4")
         sel = min(int(sel_size), self.n_global)
         ops = self.ops
-        if 1 <= sel <= getattr(ops, "max_head", 0):
+        fused = 1 <= sel <= getattr(ops, "max_head", 0) and hasattr(ops, "shard_finish_enqueue")
+        if fused:
             rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel)
-            own = hasattr(ops, "shard_finish_own")
-            out = (ops.shard_finish_own if own else ops.shard_finish)(self.world, sel, self._all_gather(rec), sel)
+            ops.shard_finish_enqueue(self.world, sel, self._all_gather(rec), sel)
+        return (strat, sel_size, sel, fused)
+
+    def _unpack(self, out, strat, sel, length, cnt, copy, big_m):
+        valid = min(sel, length)
+        if copy:
+            ids, scores = out["idx"][:valid].copy(), out["score"][:valid] + (_BIG_M if big_m else 0.0)
+        else:
+            ids, scores = out["idx"][:valid], out["score"][:valid]
+            if big_m:
+                scores += _BIG_M
+        w = out["n_own"]
+        pos = out["pos"][:w]
+        w = int(np.searchsorted(pos, valid))          # (pads beyond the list never carry rows; be explicit)
+        mine = np.zeros(valid, dtype=bool)
+        mine[pos[:w]] = True
+        return dict(ids=ids, scores=scores, mine=mine, lam=out["lam"][:w], coef=out["coef"][:w], rhs=out["rhs"][:w],
+                    ks=out["ks"][:w], counters=cnt)
+
+    def end_round(self, token, copy=True):
+        strat, sel_size, sel, fused = token
+        ops = self.ops
+        if fused:
+            out = ops.shard_finish_wait()
             hdr = out["headers"]
             g = (hdr[0] if hdr.shape[0] == 1 else hdr.sum(axis=0)).tolist()
             length = int(g[0])
             # g[4] != 0: some shard's selection gave up (csrc/topk.hip), its record is void
             if int(g[4]) == 0 and (strat != 4 or length >= sel):
-                valid = min(sel, length)
                 cnt = dict(nb_violated=int(g[1]), nb_positive=int(g[2]))
                 if strat == 4:
                     cnt.update(strong=sel, violated=sel)
-                if copy or not own:
-                    ids, scores = out["idx"][:valid].copy(), out["score"][:valid] + (_BIG_M if strat == 4 else 0.0)
-                else:
-                    ids, scores = out["idx"][:valid], out["score"][:valid]
-                    if strat == 4:
-                        scores += _BIG_M
-                res = dict(ids=ids, scores=scores, new_strat=strat, n_total=self.n_global if strat != 1 else length, counters=cnt)
-                if own:      # rows compacted by the library: views of its host block, valid until the next round
-                    w = out["n_own"]
-                    mine = np.zeros(valid, dtype=bool)
-                    mine[out["pos"][:w]] = True
-                    res.update(mine=mine, lam=out["lam"][:w], coef=out["coef"][:w], rhs=out["rhs"][:w], ks=out["ks"][:w])
-                else:
-                    mine = out["ks"][:valid] > 0
-                    res.update(mine=mine, lam=out["lam"][:valid][mine], coef=out["coef"][:valid][mine],
-                               rhs=out["rhs"][:valid][mine], ks=out["ks"][:valid][mine])
+                res = self._unpack(out, strat, sel, length, cnt, copy, strat == 4)
+                res.update(new_strat=strat, n_total=self.n_global if strat != 1 else length)
+                self.path_counts["common"] += 1
                 return res
+            if int(g[4]) == 0 and strat == 4 and hasattr(ops, "shard_finish_enqueue"):
+                # fewer than sel strong candidates overall (`length` of them): the scan visits every entry
+                # (cut_select_qp.py:606-623), each shard's combined ranking is a sub-list of the global one
+                rec = ops.shard_head(_capi.PART_COMBALL, sel)
+                ops.shard_finish_enqueue(self.world, sel, self._all_gather(rec), sel, fields=3)
+                out = ops.shard_finish_wait()
+                hdr = out["headers"]
+                g2 = (hdr[0] if hdr.shape[0] == 1 else hdr.sum(axis=0)).tolist()
+                if int(g2[4]) == 0:
+                    strong, violated = length, int(g2[1])            # every violated entry is seen by the scan
+                    cnt = dict(nb_violated=int(g2[1]), nb_positive=int(g2[2]), strong=strong, violated=violated)
+                    res = self._unpack(out, strat, sel, self.n_global, cnt, copy, False)
+                    res.update(new_strat=1 if strong / sel < violated / self.n_global else 4, n_total=self.n_global)     # :630
+                    self.path_counts["comball"] += 1
+                    return res
+        # last resort (a selection that declared itself void, heads beyond the fused path's 16384): the unfused route
+        self.path_counts["unfused"] += 1
         if hasattr(ops, "ensure_scored"):
             ops.ensure_scored(strat)
         res = self.select(strat, sel_size)
@@ -286,20 +329,33 @@ class ShardedQCQPRound(object):
             raise ValueError("strategy must be 1, 2 or 4")
         so, sc = self.sel_obj, self.sel_cons
         new_strat, n_obj, nb_opt = strat, 0, 0
-        a = b = None
-        if so is not None and so.n_global > 0:
+        a = b = ta = tb = None
+        have_a = so is not None and so.n_global > 0
+        # Both covers' halves are enqueued before the first host wait.  How many entries of B the round takes depends on
+        # the length of A's list (:79); under strategies 2 / 4 that is the objective cover's size, known beforehand,
+        # under strategy 1 the number of its violated candidates: B is then asked for sel_size and trimmed.
+        rest_bound = sel_size - (min(so.n_global, sel_size) if (have_a and strat != 1) else 0)
+        if have_a:
             so.ops.scorer.set_point(vars_values)
-            a = so.select_round(strat, sel_size)
-            # detach: the views belong to the handle's pinned block and the next call reuses it
-            a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in a.items()}
+            ta = so.begin_round(strat, sel_size)
+        if rest_bound > 0 and sc is not None and sc.n_global > 0:
+            sc.ops.scorer.set_point(vars_values)
+            tb = sc.begin_round(1, rest_bound)
+        if ta is not None:
+            a = so.end_round(ta)
             n_obj = len(a["ids"])                        # min(len(comb_obj), sel_size), :79
             new_strat = a["new_strat"]
             if strat != 1:
                 nb_opt = int(np.count_nonzero(a["scores"] > _BIG_M))       # :85-88 (entries beyond the head carry no +BIG_M)
         rest = sel_size - n_obj
-        if rest > 0 and sc is not None and sc.n_global > 0:
-            sc.ops.scorer.set_point(vars_values)
-            b = sc.select_round(1, rest)
+        if tb is not None:
+            b = sc.end_round(tb)
+            if len(b["ids"]) > rest:                     # strategy 1: A's list turned out longer than nothing
+                w = int(np.count_nonzero(b["mine"][:rest]))
+                b = dict(b, ids=b["ids"][:rest], scores=b["scores"][:rest], mine=b["mine"][:rest], lam=b["lam"][:w],
+                         coef=b["coef"][:w], rhs=b["rhs"][:w], ks=b["ks"][:w])
+            if rest <= 0:
+                b = None
         ids = np.concatenate([a["ids"] if a else np.empty(0, np.int64), b["ids"] if b else np.empty(0, np.int64)])
         scores = np.concatenate([a["scores"] if a else np.empty(0), b["scores"] if b else np.empty(0)])
         is_obj = np.zeros(ids.shape[0], dtype=bool)

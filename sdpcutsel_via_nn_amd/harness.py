@@ -31,7 +31,8 @@ class _RowStore(object):
     row 4).  ``rows`` materialises SparsePair objects only if somebody asks for them."""
 
     def __init__(self):
-        self._blocks, self.rhs, self.senses = [], [], []
+        self._blocks = []
+        self._rhs, self._senses = [], []       # per block: list / array of right-hand sides; list of senses or (sense, count)
         self._n = 0
 
     def add(self, lin_expr=(), rhs=(), senses=()):
@@ -39,17 +40,32 @@ class _RowStore(object):
         lin_expr = list(lin_expr)
         self._blocks.append(("rows", lin_expr))
         self._n += len(lin_expr)
-        self.rhs.extend(rhs)
-        self.senses.extend(senses)
+        self._rhs.append(list(rhs))
+        self._senses.append(list(senses))
         return range(start, self._n)
 
     def add_csr(self, indptr, indices, values, rhs, sense):
+        """a block of rows as arrays; the store keeps the arrays it is given (no per-row objects, no lists)"""
         start, r = self._n, len(indptr) - 1
         self._blocks.append(("csr", np.asarray(indptr), np.asarray(indices), np.asarray(values)))
         self._n += r
-        self.rhs.extend(np.asarray(rhs, dtype=np.float64).tolist())
-        self.senses.extend([sense] * r)
+        self._rhs.append(np.asarray(rhs, dtype=np.float64))
+        self._senses.append((sense, r))
         return range(start, self._n)
+
+    @property
+    def rhs(self):
+        out = []
+        for b in self._rhs:
+            out.extend(b.tolist() if isinstance(b, np.ndarray) else b)
+        return out
+
+    @property
+    def senses(self):
+        out = []
+        for b in self._senses:
+            out.extend([b[0]] * b[1] if isinstance(b, tuple) else b)
+        return out
 
     def get_num(self):
         return self._n

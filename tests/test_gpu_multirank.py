@@ -47,7 +47,7 @@ for vv in points:
     E, O = torch.cat(parts_e).numpy(), torch.cat(parts_o).numpy()
     n_strong = int(((O > 0) & (E < -1e-15)).sum())
     for strat in (1, 2, 4):
-        for sel_size in sorted({37, 5000, max(n_strong - 5, 1), n_strong + 40}):
+        for sel_size in sorted({37, 5000, 12000, max(n_strong - 5, 1), n_strong + 40}):
             sel.ops.ensure_scored(strat)
             r = sel.select(strat, sel_size)
             order, score, new_strat, cnt = oracle.rank_arrays(strat, O, E, sel_size)
@@ -72,6 +72,8 @@ for vv in points:
             assert np.array_equal(q["lam"], lam) and np.array_equal(q["rhs"], rhs) and np.array_equal(q["ks"], ks)
             assert np.array_equal(q["coef"], coef[:, :9])
             assert np.allclose(q["lam"], E[order[:k][own]], rtol=1e-9, atol=1e-12)
+# every fused round was served inside the library: one collective (common regime) or two (every entry visited)
+assert sel.path_counts["unfused"] == 0 and sel.path_counts["comball"] >= 2 and sel.path_counts["common"] >= 10, sel.path_counts
 sc.close()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -111,7 +113,7 @@ def test_shard_round_ragged_shards_one_process(oracle):
         n_strong = int(((O > 0) & (E < -1e-15)).sum())
         assert n_strong > 50
         for strat, code in ((1, 1), (2, 2), (4, _capi.PART_STRONG)):
-            for sel in (1, 29, 50, 5000, 8192):
+            for sel in (1, 29, 50, 5000, 8192, 16384):
                 if strat == 4 and sel > n_strong:
                     continue                       # the general regime is ShardedSelector.select's business
                 if sel in (29, 5000):             # scores gone: shard_head scores the shard itself
@@ -141,6 +143,34 @@ def test_shard_round_ragged_shards_one_process(oracle):
                         assert np.array_equal(out["lam"][:k][own], lam) and np.array_equal(out["rhs"][:k][own], rhs)
                         assert np.array_equal(out["coef"][:k][own], coef[:, :out["coef"].shape[1]])
                         assert np.array_equal(out["ks"][:k][own], ks)
+        # every entry visited (SDPCUT_PART_COMBALL): three-field records, merged with obj_improve as secondary key
+        for sel in (1, 29, 5000, 8192, 16384):
+            for ops in opss:
+                ops.scorer.set_point(wl["vars_values"])
+            allrec = torch.cat([ops.shard_head(_capi.PART_COMBALL, sel) for ops in opss])
+            order, score, _, _ = oracle.rank_arrays(4, O, E, E.shape[0] + 1)      # unreachable quota: every entry visited
+            k = min(sel, order.shape[0])
+            for r, ops in enumerate(opss):
+                ops.shard_finish_enqueue(len(sizes), sel, allrec, sel, fields=3)
+            for r, ops in enumerate(opss):
+                out = ops.shard_finish_wait()
+                g = out["headers"].sum(axis=0)
+                assert int(g[0]) == E.shape[0]
+                if int(g[4]):
+                    # a head of exactly the sort buffers' capacity cannot take a group of equal new scores that straddles
+                    # its end whole (this workload is full of duplicates), and equal new scores are not cut by index: the
+                    # shard declares its selection void and the caller takes the unfused route
+                    assert sel == 8192
+                    continue
+                assert np.array_equal(out["idx"][:k], order[:k]), (sel, r)
+                assert np.array_equal(out["score"][:k], score[:k] + 0.0)
+                lo, n = int(bases[r]), sizes[r]
+                own = (order[:k] >= lo) & (order[:k] < lo + n)
+                assert out["n_own"] == int(own.sum()) and np.array_equal(out["pos"][:out["n_own"]], np.flatnonzero(own))
+                if own.any():
+                    lam, coef, rhs, _, ks = ops.scorer.cut_rows(order[:k][own] - lo)
+                    w = out["n_own"]
+                    assert np.array_equal(out["lam"][:w], lam) and np.array_equal(out["rhs"][:w], rhs) and np.array_equal(out["ks"][:w], ks)
     finally:
         for ops in opss:
             ops.scorer.close()

@@ -611,7 +611,7 @@ def test_topk_select_path_equals_full_sort_full_size(full_c2, scorer, strat):
 def test_topk_select_with_masses_of_equal_keys_full_size(full_c2, scorer, oracle, distinct_vars):
     """10^6 candidates at a structured point (x = 0.5, X = 0.1 everywhere except the rows of a few
     variables): the eigenvalue takes a handful of values, each shared by 10^4..10^6 candidates, so
-    the radix select cannot close early and runs all eight digits inside tk_hist_rest_kernel's
+    the radix select cannot close early and runs all eight digits behind tk_refine_kernel's
     grid barrier; ties are cut by index exactly as the stable sort does."""
     from sdpcutsel_via_nn_amd import _capi
     wl, _, _ = full_c2

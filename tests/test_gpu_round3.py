@@ -153,8 +153,6 @@ def test_round_csr_equals_the_padded_rows(pkg, sizes, count, nb_vars, sel, strat
         indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
         assert np.array_equal(c["indptr"], indptr) and np.array_equal(c["indices"], ind) and np.array_equal(c["values"], val)
         assert np.array_equal(c["rhs"], rhs[keep])
-        if strat == 2 and count >= 3000:
-            assert 0 < keep.size < c["idx"].shape[0]       # the optimality head holds non-violated entries: the compaction is exercised
         # the same point again without an upload (vars_values = NULL)
         c2 = sc.round_csr(strat, sel, point=None, copy=True)
         for f in ("idx", "score", "indptr", "indices", "values", "rhs", "row_entry"):
@@ -179,6 +177,7 @@ def test_round_csr_general_regime_and_short_lists(pkg, oracle):
         x = wl["vars_values"][L:]
         iu = np.triu_indices(n)
         psd = np.concatenate([np.minimum(x[iu[0]], x[iu[1]]), x])          # X = min(x_i, x_j) is PSD: nothing violated
+        partial = 0
         for vv, sel in ((wl["vars_values"], 5000), (psd, 5000), (0.999 * psd + 0.001 * wl["vars_values"], 3000)):
             for strat in (4, 1, 2):
                 r, lam, coef, rhs, cols, ks = _padded_reference(sc, strat, sel, vv)
@@ -188,6 +187,8 @@ def test_round_csr_general_regime_and_short_lists(pkg, oracle):
                 indptr, ind, val = rows_to_csr(coef[keep], cols[keep], ks[keep])
                 assert np.array_equal(c["row_entry"], keep) and np.array_equal(c["indptr"], indptr)
                 assert np.array_equal(c["indices"], ind) and np.array_equal(c["values"], val) and np.array_equal(c["rhs"], rhs[keep])
+                partial += 0 < keep.size < c["idx"].shape[0]
+        assert partial >= 1          # heads with violated AND non-violated entries: the compaction skipped rows
         r = sc.round_csr(1, 5000, point=psd)
         assert r["idx"].shape[0] == 0 and r["rhs"].shape[0] == 0 and r["n_total"] == 0 and r["indptr"].tolist() == [0]
     finally:
@@ -230,8 +231,6 @@ def test_dropin_pair_hands_over_the_fused_rows(pkg, strat):
         db, cb, lb = st_b.csr_parts()
         assert np.array_equal(da, db) and np.array_equal(ca, cb) and np.array_equal(la, lb)
         assert st_a.rhs == st_b.rhs and st_a.senses == st_b.senses
-        if strong_only and strat != 1:
-            assert nb_a < 5000
 
     class RefStore(object):                   # the reference's LP surface: only add(lin_expr=, rhs=, senses=)
         def __init__(self):
@@ -292,3 +291,74 @@ def test_qcqp_round_keeps_the_fused_rows_through_slices(pkg, oracle, golden_qcqp
         assert calls == []
     finally:
         _capi.Scorer.cut_rows = orig
+
+
+# ----------------------------------------------------------------------------- selection paths, LP point buffer
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_selection_without_in_kernel_waits_equals_the_fused_one(pkg, strat):
+    """SDPCUT_OPT_FUSED_TAIL = 0 (one launch per digit, the path that answers when a bounded wait of the fused kernel
+    expires) == the fused selection: spread-out scores, masses of equal keys (duplicated candidates), short lists."""
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    for nb_vars, count, sel in ((100, 400000, 5000), (12, 300000, 5000), (30, 6000, 3000), (9, 200000, 16000)):
+        wl = synthetic.make_workload(nb_vars=nb_vars, k=3, count=count, seed=41)
+        res = {}
+        for fused in (1, 0):
+            sc = pkg.Scorer(0)
+            try:
+                sc.set_builtin_networks(3)
+                sc.set_option(_capi.OPT_FUSED_TAIL, fused)
+                sc.set_instance(nb_vars, wl["Q_arr"])
+                sc.set_candidates(wl["set_inds"], wl["ks"])
+                res[fused] = sc.select_round(strat, sel, point=wl["vars_values"])
+                assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+            finally:
+                sc.close()
+        for f in ("idx", "score", "lam", "coef", "rhs", "ks"):
+            assert np.array_equal(res[1][f], res[0][f]), (nb_vars, f)
+        assert res[1]["n_total"] == res[0]["n_total"] and res[1]["new_strat"] == res[0]["new_strat"]
+        assert res[1]["counters"] == res[0]["counters"]
+
+
+def test_lp_point_through_the_pinned_buffer(pkg):
+    """sdpcut_point_buffer: the point written in place into the handle's staging block gives the round the same results
+    as the point handed over in an ordinary array -- also after the instance (and with it the block) changed."""
+    from sdpcutsel_via_nn_amd import synthetic
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(3)
+        for nb_vars, count in ((40, 50000), (200, 80000), (40, 20000)):
+            wl = synthetic.make_workload(nb_vars=nb_vars, k=3, count=count, seed=8)
+            sc.set_instance(nb_vars, wl["Q_arr"])
+            sc.set_candidates(wl["set_inds"], wl["ks"])
+            a = sc.select_round(4, 2000, point=wl["vars_values"])
+            buf = sc.point_buffer()
+            assert buf.shape == wl["vars_values"].shape
+            buf[:] = 0.0
+            b0 = sc.select_round(4, 2000, point=buf)
+            assert b0["n_total"] == count and not np.array_equal(b0["idx"], a["idx"])      # really another point
+            buf[:] = wl["vars_values"]
+            b = sc.select_round(4, 2000, point=buf)
+            c = sc.round_csr(4, 2000, point=buf, copy=True)
+            for f in ("idx", "score", "lam", "coef", "rhs"):
+                assert np.array_equal(a[f], b[f]), f
+            assert np.array_equal(c["idx"], a["idx"])
+    finally:
+        sc.close()
+
+
+def test_triangle_separation_without_in_kernel_waits(pkg):
+    from sdpcutsel_via_nn_amd import _capi, harness
+    inst = harness.parse_boxqp(os.path.join(GOLDEN, "instances", "spar125-075-1.in"))
+    vv = harness.random_mccormick_point(inst["nb_vars"], np.random.default_rng(2))
+    out = {}
+    for fused in (1, 0):
+        sc = pkg.Scorer(0)
+        try:
+            sc.set_option(_capi.OPT_FUSED_TAIL, fused)
+            sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+            sc.tri_preprocess(inst["adj"])
+            sc.set_point(vv)
+            out[fused] = sc.tri_separate(10000)
+        finally:
+            sc.close()
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1]) and out[1][2] == out[0][2] > 10000

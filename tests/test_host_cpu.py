@@ -187,27 +187,42 @@ class FakeOps(object):
         o = np.lexsort(keys)[:count_out]
         return scores[o], ids[o]
     # fused round: packed record / merge + rows of the own entries (row = the candidate's lam only)
-    max_head = 8192
+    max_head = 16384
     def shard_head(self, strat, count):
-        s, i, _, total, _ = self.local_head(strat, count, count)
         n = self.obj.shape[0]
-        hdr = [n if strat == 2 else total, int((self.lam < oracle.THRES_NEG_EIGVAL).sum()), int((self.obj > 0).sum()),
-               min(count, total), 0, 0, 0, 0]
+        nviol, npos = int((self.lam < oracle.THRES_NEG_EIGVAL).sum()), int((self.obj > 0).sum())
+        if strat == _capi.PART_COMBALL:      # PART_COMBALL: every entry visited -> the shard's own combined ranking, obj_improve as third field
+            order, score, _, _ = oracle.rank_arrays(4, self.obj, self.lam, n + 1)
+            w = min(count, n)
+            s = torch.full((count,), float("-inf"), dtype=torch.float64); i = torch.full((count,), _PAD_ID, dtype=torch.int64)
+            x = torch.full((count,), float("-inf"), dtype=torch.float64)
+            s[:w] = torch.from_numpy(score[:w].copy()); i[:w] = torch.from_numpy(order[:w] + self.base)
+            x[:w] = torch.from_numpy(self.obj[order[:w]].copy())
+            hdr = [n, nviol, npos, w, 0, 0, 0, 0]
+            return torch.cat([torch.tensor(hdr, dtype=torch.int64), s.view(torch.int64), i, x.view(torch.int64)])
+        s, i, _, total, _ = self.local_head(strat, count, count)
+        hdr = [n if strat == 2 else total, nviol, npos, min(count, total), 0, 0, 0, 0]
         return torch.cat([torch.tensor(hdr, dtype=torch.int64), s.view(torch.int64), i])
     def rows_of(self, ids):
         n = self.obj.shape[0]
         mine = (ids >= self.base) & (ids < self.base + n)
         c = int(mine.sum())
         return mine, self.lam[ids[mine] - self.base], np.zeros((c, 9)), np.zeros(c), np.full(c, 3, dtype=np.int32)
-    def shard_finish(self, world, count, allrec, sel):
+    def shard_finish_enqueue(self, world, count, allrec, sel, fields=2):
         a = allrec.view(world, -1).numpy()
         s = np.ascontiguousarray(a[:, 8:8 + count]).reshape(-1).view(np.float64)
-        i = np.ascontiguousarray(a[:, 8 + count:]).reshape(-1)
-        o = np.lexsort((i, -s))[:sel]
+        i = np.ascontiguousarray(a[:, 8 + count:8 + 2 * count]).reshape(-1)
+        if fields == 3:
+            x = np.ascontiguousarray(a[:, 8 + 2 * count:]).reshape(-1).view(np.float64)
+            o = np.lexsort((i, -x, -s))[:sel]
+        else:
+            o = np.lexsort((i, -s))[:sel]
         mine, lam_m, _, _, _ = self.rows_of(i[o])
-        lam = np.full(sel, np.nan); lam[mine] = lam_m
-        return dict(headers=a[:, :8].copy(), idx=i[o], score=s[o], lam=lam, coef=np.zeros((sel, 9)), rhs=np.zeros(sel),
-                    ks=np.where(mine, 3, 0).astype(np.int32))
+        w = int(mine.sum())
+        self._pending = dict(headers=a[:, :8].copy(), idx=i[o], score=s[o].copy(), lam=lam_m, coef=np.zeros((w, 9)), rhs=np.zeros(w),
+                             ks=np.full(w, 3, dtype=np.int32), pos=np.flatnonzero(mine).astype(np.int32), n_own=w)
+    def shard_finish_wait(self):
+        return self._pending
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
