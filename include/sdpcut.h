@@ -161,6 +161,17 @@ int sdpcut_set_candidates_philox(sdpcut_handle h, int32_t k, int64_t N, uint64_t
 int sdpcut_set_candidates_cover(sdpcut_handle h, const uint8_t *adjacency, int32_t dim, int64_t max_subs,
                                 int64_t *count_out);
 
+/*
+ * The two candidate lists of a QCQP instance (replaces __get_vertex_cover, cut_select_qcqp.py:314-334, including its
+ * list-membership intersection): h_in receives the sub-problems of the cover of `adjacency_all` (objective + all
+ * constraints) that also belong to the cover of `adjacency_obj` (self._agg_list, :331), h_out the others
+ * (agg_list_cons, :332-333), both in the order of the `adjacency_all` enumeration.  Everything happens on the device
+ * (two enumerations, one binary search per set, prefix sums); the handles must sit on the same device and hold the
+ * same instance (sdpcut_set_instance).  Adjacencies as in sdpcut_set_candidates_cover.
+ */
+int sdpcut_set_candidates_cover_split(sdpcut_handle h_in, sdpcut_handle h_out, const uint8_t *adjacency_obj,
+                                      const uint8_t *adjacency_all, int32_t dim, int64_t *n_in, int64_t *n_out);
+
 /* Index sets of `count` candidates given by LOCAL index, device -> host: set_inds_out [count][5]
  * padded with -1, ks_out [count] (0 for an index outside the list).  For lists that were generated
  * or enumerated on the device: the host names only the few thousand selected candidates. */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "sdpcut_set_candidates": [_vp, _c.c_int64, _i32p, _c.c_int32, _i32p, _c.c_int64],
     "sdpcut_set_candidates_philox": [_vp, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_int64],
     "sdpcut_set_candidates_cover": [_vp, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i64p],
+    "sdpcut_set_candidates_cover_split": [_vp, _vp, _c.POINTER(_c.c_uint8), _c.POINTER(_c.c_uint8), _c.c_int32, _i64p, _i64p],
     "sdpcut_get_candidates": [_vp, _c.c_int64, _i64p, _i32p, _i32p],
     "sdpcut_set_builtin_networks": [_vp, _c.c_int],
     "sdpcut_set_point": [_vp, _dp],
@@ -254,6 +255,23 @@ class Scorer(object):
             self.N, self.base = int(cnt.value), 0
             self.row_len = int(dim) * (int(dim) + 3) // 2      # upper bound: the largest size present is <= dim
         return int(cnt.value)
+
+    def set_candidates_cover_split(self, other, adjacency_obj, adjacency_all, dim):
+        """The two covers of a QCQP instance (cut_select_qcqp.py:314-334) on the device: this handle gets the sub-problems
+        of the cover of `adjacency_all` that also belong to the cover of `adjacency_obj`, `other` the rest
+        -> (count of this handle, count of `other`)"""
+        ao = np.ascontiguousarray(np.asarray(adjacency_obj) != 0, dtype=np.uint8)
+        aa = np.ascontiguousarray(np.asarray(adjacency_all) != 0, dtype=np.uint8)
+        if ao.shape != (self.nb_vars, self.nb_vars) or aa.shape != ao.shape:
+            raise ValueError("adjacency must be [n, n]")
+        n_in, n_out = _c.c_int64(0), _c.c_int64(0)
+        u8 = _c.POINTER(_c.c_uint8)
+        self._check(self._lib.sdpcut_set_candidates_cover_split(self._h, other._h, ao.ctypes.data_as(u8), aa.ctypes.data_as(u8), int(dim),
+                                                                ctypes.byref(n_in), ctypes.byref(n_out)))
+        for sc, n in ((self, n_in.value), (other, n_out.value)):
+            sc.N, sc.base = int(n), 0
+            sc.row_len = int(dim) * (int(dim) + 3) // 2
+        return int(n_in.value), int(n_out.value)
 
     def get_candidates(self, local_idx):
         """-> (set_inds int32 [count, 5] padded with -1, ks int32 [count]) of candidates by local index"""

@@ -35,52 +35,169 @@ struct EigArgs {
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
 };
 
-template <int K>
-__device__ __forceinline__ double eig_tile(const EigArgs &A, int64_t tile, bool *valid_out, int32_t *out_idx)
+// ---- re-packing the lanes that have not converged ------------------------------------------------------------
+// Cyclic Jacobi needs 3-5 sweeps on these matrices, and a wave runs as many as its SLOWEST lane: on the c2 list 72 %
+// of the 4x4 matrices are done after 4 sweeps and 1 % need a fifth, which 47 % of the waves then run for everybody
+// (mean over lanes 3.74 sweeps, mean over waves 4.47); 77 % of the 5x5 matrices need 4 sweeps, 23 % need 5, and 96 %
+// of the waves run 5.  So a tile stops after R sweeps, the lanes that have not converged put their matrices into LDS
+// -- packed, in any order -- and only as many waves as they fill continue.  Every matrix goes through exactly the
+// rotations it would have gone through alone: lambda_min is bit-for-bit what jacobi_eig returns.
+// Measured on 1e6 candidates per size (tools/gpu_eig_abl.sh, profiles/r03_eig_kernel_variants.txt): 5x5 matrices 85.7 -> 77.6 us
+// (-9.5 %), 6x6 141.6 -> 136.9 (-3 %); 4x4 matrices gain nothing either way (re-pack after 3 sweeps: 73 % of the lanes
+// go through LDS, 48.6 vs 47.0 us; after 4: 1 % do, 47.7 -- the barrier that couples the four waves costs what the
+// fifth sweep of half the waves does), so 2- and 3-variable tiles run the plain loop.
+constexpr int eig_pack_sweeps(int k) { return k <= 3 ? JACOBI_MAX_SWEEPS : (k == 4 ? 4 : 5); }      // sweeps before the re-pack
+constexpr int eig_pack_cap(int k) { return k <= 3 ? 0 : (k == 4 ? 128 : 64); }      // packed lanes LDS holds (the rest goes on in place)
+template <int K> struct EigPack {
+    static constexpr int D = K + 1;
+    static constexpr int NS = D * (D + 1) / 2 + 1;       // upper triangle + the tolerance
+    static constexpr int R = eig_pack_sweeps(K);
+    static constexpr int CAP = eig_pack_cap(K);
+};
+constexpr int eig_pack_doubles(int kmax)
 {
-    const int64_t n = A.n[K];
-    const int64_t c = tile * 256 + threadIdx.x;
-    const bool valid = c < n;
-    const int64_t cc = valid ? c : n - 1;
-    Cand<K> cd;
-    gather_candidate<K>(cd, A.set[K], n, cc, A.vars, nullptr, A.nv, A.L, false);
-    *out_idx = A.orig[K][cc];
-    *valid_out = valid;
-    return candidate_eigmin<K>(cd);
+    int m = 0;
+    for (int k = 2; k <= kmax; ++k) {
+        const int d = k + 1, ns = d * (d + 1) / 2 + 1;
+        const int cap = eig_pack_cap(k);
+        m = ns * cap > m ? ns * cap : m;
+    }
+    return m > 0 ? m : 1;
+}
+#ifndef SDPCUT_EIG_REPACK
+#define SDPCUT_EIG_REPACK 1
+#endif
+
+template <int K, bool FUSE>
+__device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol)
+{
+    if (live) A.eig_out[out_idx] = lam;
+    if constexpr (FUSE) {
+        const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
+        hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
+        c_viol += viol;
+    }
 }
 
-// waves per SIMD the kernel is compiled for (hipcc -Rpass-analysis=kernel-resource-usage: 40 / 54 / 64 / 82 VGPRs for
-// KMAX = 2 / 3 / 4 / 5 with the histogram, no scratch): 8 waves up to 5x5 matrices, 5 with the 6x6 ones
-template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 4 ? 8 : 5; };
+// one tile of 256 candidates of size K (index set s, output slot out_idx of this lane's candidate already loaded);
+// cnt = this tile's packed-lane counter (zero on entry)
+template <int K, bool FUSE>
+__device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K], int32_t out_idx, bool valid, double *s_state,
+                                         int32_t *s_out, uint32_t *cnt, uint32_t *tk_hist, uint32_t &c_viol)
+{
+    using P = EigPack<K>;
+    constexpr int D = P::D;
+    Cand<K> cd;
+    gather_candidate<K>(cd, s, A.vars, nullptr, A.nv, A.L, false);
+    double a[D][D], v[D][D];
+    fill_lifted<K>(a, cd.x, cd.X);
+    const double tol = jacobi_tol<D, false>(a);
+    if constexpr (SDPCUT_EIG_REPACK && P::CAP > 0) {
+    jacobi_sweeps<D, false>(a, v, tol, P::R);
+    const bool more = valid && !jacobi_converged<D>(a, tol);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(more);
+    uint32_t base = 0;
+    if (lane == 0 && m) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const bool packed = more && slot < (uint32_t)P::CAP;
+    if (packed) {
+        int j = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = p; q < D; ++q) s_state[(j++) * P::CAP + slot] = a[p][q];
+        s_state[j * P::CAP + slot] = tol;
+        s_out[slot] = out_idx;
+    }
+    if (more && !packed) jacobi_sweeps<D, false>(a, v, tol, JACOBI_MAX_SWEEPS - P::R);      // LDS full: this lane goes on in place
+    eig_emit<K, FUSE>(A, diag_min<D>(a), out_idx, valid && !packed, tk_hist, c_viol);
+    __syncthreads();
+    const uint32_t total = *cnt < (uint32_t)P::CAP ? *cnt : (uint32_t)P::CAP;
+    if ((threadIdx.x & ~63u) < total) {      // uniform per wave: only the waves the packed lanes fill go on
+        const bool mine = threadIdx.x < total;
+        const uint32_t sl = mine ? threadIdx.x : 0;
+        int j = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = p; q < D; ++q) { a[p][q] = s_state[(j++) * P::CAP + sl]; a[q][p] = a[p][q]; }
+        const double tol2 = s_state[j * P::CAP + sl];
+        const int32_t out2 = s_out[sl];
+        if (mine) jacobi_sweeps<D, false>(a, v, tol2, JACOBI_MAX_SWEEPS - P::R);
+        eig_emit<K, FUSE>(A, diag_min<D>(a), out2, mine, tk_hist, c_viol);
+    }
+    } else {
+        jacobi_sweeps<D, false>(a, v, tol, JACOBI_MAX_SWEEPS);
+        eig_emit<K, FUSE>(A, diag_min<D>(a), out_idx, valid, tk_hist, c_viol);
+    }
+}
+
+// this workgroup's tiles of size class K: global tiles [lo, hi) of the launch's list, every gridDim.x-th from blockIdx.x
+template <int K, bool FUSE>
+__device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t hi, double *s_state, int32_t *s_out, uint32_t *s_packed,
+                                          int &par, uint32_t *tk_hist, uint32_t &c_viol)
+{
+    const int64_t G = gridDim.x, n = A.n[K];
+    int64_t t = blockIdx.x;
+    if (t < lo) t += (lo - t + G - 1) / G * G;
+    if (t >= hi) return;      // uniform
+    int32_t s_nxt[K];
+    int32_t orig_nxt;
+    {
+        const int64_t c = (t - lo) * 256 + threadIdx.x, cc = c < n ? c : n - 1;
+        load_index_set<K>(s_nxt, A.set[K], n, cc);
+        orig_nxt = A.orig[K][cc];
+    }
+    for (; t < hi; t += G, par ^= 1) {
+        int32_t s_cur[K];
+#pragma unroll
+        for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
+        const int32_t out_idx = orig_nxt;
+        const bool valid = (t - lo) * 256 + threadIdx.x < n;
+        if (t + G < hi) {      // uniform
+            const int64_t c = (t + G - lo) * 256 + threadIdx.x, cc = c < n ? c : n - 1;
+            load_index_set<K>(s_nxt, A.set[K], n, cc);
+            orig_nxt = A.orig[K][cc];
+        }
+        eig_tile<K, FUSE>(A, s_cur, out_idx, valid, s_state, s_out, &s_packed[par], tk_hist, c_viol);
+        // the next tile counts into the other word (zero since the barrier of the tile before this one); this tile's is
+        // cleared behind the barrier that ends its use, in front of the barrier of the next tile
+        __syncthreads();
+        if (threadIdx.x == 0) s_packed[par] = 0;
+    }
+}
+
+// waves per SIMD the kernel is compiled for (hipcc -Rpass-analysis=kernel-resource-usage)
+#ifndef SDPCUT_EIG_W
+#define SDPCUT_EIG_W 6
+#endif
+template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? 8 : (KMAX == 4 ? SDPCUT_EIG_W : 5); };
 
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
     __shared__ uint32_t tk_hist[256];
     __shared__ uint32_t tk_cnt;
+    __shared__ double s_state[eig_pack_doubles(KMAX)];
+    __shared__ int32_t s_out[256];
+    __shared__ uint32_t s_packed[2];      // packed-lane counters of the current / the next tile
+    if (threadIdx.x < 2) s_packed[threadIdx.x] = 0;
     if constexpr (FUSE) {
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x == 0) tk_cnt = 0;
-        __syncthreads();
     }
+    __syncthreads();
     uint32_t c_viol = 0;
-    const int64_t ntiles = A.tile_end[2];
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        double lam;
-        bool valid;
-        int32_t out_idx;
-        // uniform per workgroup: which class this tile belongs to
-        if (KMAX >= 5 && t < A.tile_end[5]) lam = eig_tile<5>(A, t, &valid, &out_idx);
-        else if (KMAX >= 4 && t < A.tile_end[4]) lam = eig_tile<(KMAX >= 4 ? 4 : 2)>(A, t - A.tile_end[5], &valid, &out_idx);
-        else if (KMAX >= 3 && t < A.tile_end[3]) lam = eig_tile<(KMAX >= 3 ? 3 : 2)>(A, t - A.tile_end[4], &valid, &out_idx);
-        else lam = eig_tile<2>(A, t - A.tile_end[3], &valid, &out_idx);
-        if (valid) A.eig_out[out_idx] = lam;
-        if constexpr (FUSE) {
-            const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;
-            hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
-            c_viol += viol;
-        }
-    }
+    int par = 0;
+    // tiles of all classes form one list, largest size first; workgroup b takes tiles b, b + G, ... -- class by class, so that
+    // the index set of its NEXT tile (HBM) is requested before the current one is worked on (the first of the two dependent
+    // memory round trips of a tile off the critical path, as in score_mfma_kernel)
+    if constexpr (KMAX >= 5) eig_class<5, FUSE>(A, 0, A.tile_end[5], s_state, s_out, s_packed, par, tk_hist, c_viol);
+    if constexpr (KMAX >= 4) eig_class<4, FUSE>(A, A.tile_end[5], A.tile_end[4], s_state, s_out, s_packed, par, tk_hist, c_viol);
+    if constexpr (KMAX >= 3) eig_class<3, FUSE>(A, A.tile_end[4], A.tile_end[3], s_state, s_out, s_packed, par, tk_hist, c_viol);
+    eig_class<2, FUSE>(A, A.tile_end[3], A.tile_end[2], s_state, s_out, s_packed, par, tk_hist, c_viol);
     if constexpr (FUSE) {
         // (no ticket, nobody waits: the kernel boundary orders the atomics before the selection, see score.hip)
         for (int off = 32; off > 0; off >>= 1) c_viol += __shfl_xor((int)c_viol, off);
@@ -95,8 +212,8 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
     }
 }
 
-// workgroups launched per resident slot: a few tiles per workgroup keep the flush of the histogram rare,
-// more workgroups than slots let the dispatcher balance strips whose Jacobi needs one sweep more
+// workgroups launched per resident slot: four short-lived ones -- the dispatcher balances tiles whose Jacobi needs a sweep
+// more; one long-lived workgroup per slot with the next tile's index set in flight was measured 5 % slower
 #ifndef SDPCUT_EIG_BLOCKS_PER_SLOT
 #define SDPCUT_EIG_BLOCKS_PER_SLOT 4
 #endif

@@ -224,6 +224,53 @@ __device__ __forceinline__ void jacobi_sweep_rr(double (&a)[D][D], double (&v)[D
 #define SDPCUT_JACOBI_RR 1
 #endif
 
+// The iteration in pieces (the eigenvalue-only kernel interrupts it to re-pack the lanes that have not converged,
+// eig.hip); jacobi_eig below is their plain composition -- the same instruction sequence as before the split.
+//
+// Stopping rule on the off-diagonal mass off = sum_{p<q} a_pq^2.  Weyl: every eigenvalue is within
+// ||E||_2 <= sqrt(2 off) of a diagonal entry, whatever the gaps.
+//  * eigenvalues only (the scoring kernels): off <= 1e-29 scale^2, i.e. |d lambda| <= 4.5e-15 scale
+//    <= 2.7e-14 for these matrices (trace <= 6) in the worst case -- the parity bound is 2e-13 -- and,
+//    because the iteration converges quadratically, ~1e-20 in the typical one.  The previous
+//    threshold (1e-38) bought nothing measurable and cost the slowest lane of a wave one more sweep
+//    in about half of the strips.
+//  * with eigenvectors (cut rows, <= 5000 per round): 1e-38 as before, the vectors converge one
+//    order behind the values.
+template <int D, bool VEC>
+__device__ __forceinline__ double jacobi_tol(const double (&a)[D][D])
+{
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) scale += fabs(a[i][i]);
+    return scale * scale * (VEC ? 1e-38 : JACOBI_EIGVAL_TOL);
+}
+
+template <int D>
+__device__ __forceinline__ bool jacobi_converged(const double (&a)[D][D], double tol)
+{
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int q = p + 1; q < D; ++q) off = fma(a[p][q], a[p][q], off);
+    return !(off > tol);
+}
+
+// at most max_sweeps sweeps, each behind the convergence check
+template <int D, bool VEC>
+__device__ __forceinline__ void jacobi_sweeps(double (&a)[D][D], double (&v)[D][D], double tol, int max_sweeps)
+{
+#pragma unroll 1
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (jacobi_converged<D>(a, tol)) break;
+#if SDPCUT_JACOBI_RR
+        jacobi_sweep_rr<D, VEC>(a, v);
+#else
+        JacobiSweep<D, 0, 1, VEC>::run(a, v);
+#endif
+    }
+}
+
 // Diagonalises the symmetric matrix a (full storage, both triangles filled) in place.
 // On return the diagonal of a holds the eigenvalues (unsorted) and, if VEC, the columns
 // of v the corresponding orthonormal eigenvectors.
@@ -236,33 +283,8 @@ __device__ __forceinline__ void jacobi_eig(double (&a)[D][D], double (&v)[D][D])
 #pragma unroll
             for (int j = 0; j < D; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
     }
-    double scale = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) scale += fabs(a[i][i]);
-    // Stopping rule on the off-diagonal mass off = sum_{p<q} a_pq^2.  Weyl: every eigenvalue is within
-    // ||E||_2 <= sqrt(2 off) of a diagonal entry, whatever the gaps.
-    //  * eigenvalues only (the scoring kernels): off <= 1e-29 scale^2, i.e. |d lambda| <= 4.5e-15 scale
-    //    <= 2.7e-14 for these matrices (trace <= 6) in the worst case -- the parity bound is 2e-13 -- and,
-    //    because the iteration converges quadratically, ~1e-20 in the typical one.  The previous
-    //    threshold (1e-38) bought nothing measurable and cost the slowest lane of a wave one more sweep
-    //    in about half of the strips.
-    //  * with eigenvectors (cut rows, <= 5000 per round): 1e-38 as before, the vectors converge one
-    //    order behind the values.
-    const double tol = scale * scale * (VEC ? 1e-38 : JACOBI_EIGVAL_TOL);
-#pragma unroll 1
-    for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-        double off = 0.0;
-#pragma unroll
-        for (int p = 0; p < D; ++p)
-#pragma unroll
-            for (int q = p + 1; q < D; ++q) off = fma(a[p][q], a[p][q], off);
-        if (!(off > tol)) break;
-#if SDPCUT_JACOBI_RR
-        jacobi_sweep_rr<D, VEC>(a, v);
-#else
-        JacobiSweep<D, 0, 1, VEC>::run(a, v);
-#endif
-    }
+    const double tol = jacobi_tol<D, VEC>(a);
+    jacobi_sweeps<D, VEC>(a, v, tol, JACOBI_MAX_SWEEPS);
 }
 
 // smallest diagonal entry

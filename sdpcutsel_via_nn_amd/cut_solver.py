@@ -923,9 +923,15 @@ class CutSolverQCQP(CutSolver):
         lp.linear_constraints.add(inst["rows"], inst["rhs"], inst["senses"])
         lp.linear_constraints.add_csr(*harness.mccormick_csr(self._nb_vars, inst["adj"]), "L")
         self._load_neural_nets()
-        (So, ko), (Sc, kc) = harness.qcqp_covers(inst, dim, _capi.enumerate_cover)               # :50, :314-334
-        cover_obj = AggArrays(So, ko, self._nb_vars, self._Q_arr)
-        cover_cons = AggArrays(Sc, kc, self._nb_vars, self._Q_arr)
+        # both covers and their intersection on the device (:50, :314-334): the lists never come to the host
+        sc_o, sc_c = self._gpu_new_scorer(), self._gpu_new_scorer()
+        for sc in (sc_o, sc_c):
+            sc.set_instance(self._nb_vars, np.asarray(self._Q_arr, dtype=np.float64))
+        n_o, n_c = sc_o.set_candidates_cover_split(sc_c, inst["adj"], inst["adj_cons"], dim)
+        cover_obj = DeviceAgg(sc_o, n_o, self._nb_vars, self._Q_arr)
+        cover_cons = DeviceAgg(sc_c, n_c, self._nb_vars, self._Q_arr)
+        if strat == 5:
+            cover_obj = cover_obj.to_arrays()       # the random strategy reorders its list in place, round after round (:634-637)
         self._agg_list = cover_obj
         quota = self.selection_size(sel_size, len(cover_obj), minimum=1)                         # :55-58
         state = {"strat": strat}

@@ -362,3 +362,51 @@ def test_triangle_separation_without_in_kernel_waits(pkg):
         finally:
             sc.close()
     assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1]) and out[1][2] == out[0][2] > 10000
+
+
+# ----------------------------------------------------------------------------- QCQP covers on the device
+@pytest.mark.parametrize("name,dim", [("q_20_4_25_1", 3), ("q_20_4_25_1", 5), ("q_30_6_50_1", 3), ("q_30_6_50_1", 4),
+                                      ("q_40_8_25_1", 3), ("q_50_10_25_1", 5)])
+def test_qcqp_covers_split_on_the_device(pkg, name, dim):
+    """sdpcut_set_candidates_cover_split == the host route (two native enumerations + sorted lookup, harness.qcqp_covers)
+    == cut_select_qcqp.py:314-334: same two lists in the same order; q_50_10_25_1 with 5-variable sub-problems against the
+    reference's own cover (count and checksum in tests/golden/inst_qcqp50.npz)."""
+    import zlib
+    from sdpcutsel_via_nn_amd import _capi, harness
+    inst = harness.parse_osil(os.path.join(GOLDEN, "instances", name + ".osil"))
+    n = inst["nb_vars"]
+    (So, ko), (Sc, kc) = harness.qcqp_covers(inst, dim, _capi.enumerate_cover)
+    a, b = pkg.Scorer(0), pkg.Scorer(0)
+    try:
+        for sc in (a, b):
+            sc.set_builtin_networks(dim)
+            sc.set_instance(n, inst["Q_arr"])
+        n_in, n_out = a.set_candidates_cover_split(b, inst["adj"], inst["adj_cons"], dim)
+        assert (n_in, n_out) == (len(ko), len(kc))
+        for sc, S, k in ((a, So, ko), (b, Sc, kc)):
+            if len(k):
+                S_d, k_d = sc.get_candidates(np.arange(len(k), dtype=np.int64))
+                assert np.array_equal(S_d, S) and np.array_equal(k_d, k)
+        if name == "q_50_10_25_1":
+            g = np.load(os.path.join(GOLDEN, "inst_qcqp50.npz"))
+            assert n_out == int(g["cons_count"]) and n_in == len(g["obj_k"])
+            S_d, _ = b.get_candidates(np.arange(n_out, dtype=np.int64))
+            assert zlib.crc32(np.ascontiguousarray(S_d).tobytes()) == int(g["cons_crc"])
+        # the split lists are live candidate lists: a round on each
+        vv = harness.random_mccormick_point(n, np.random.default_rng(4))
+        for sc, S, k in ((a, So, ko), (b, Sc, kc)):
+            if len(k) == 0:
+                continue
+            r = sc.round_csr(1, 50, point=vv)
+            ref = pkg.Scorer(0)
+            try:
+                ref.set_builtin_networks(dim)
+                ref.set_instance(n, inst["Q_arr"])
+                ref.set_candidates(S, k)
+                q = ref.round_csr(1, 50, point=vv)
+                assert np.array_equal(r["idx"], q["idx"]) and np.array_equal(r["score"], q["score"]) and np.array_equal(r["values"], q["values"])
+            finally:
+                ref.close()
+    finally:
+        a.close()
+        b.close()
