@@ -46,11 +46,16 @@ HBM_PEAK_GBS = 8000.0
 KERNEL_SHAPES = {2: "2, 64, 3", 3: "3, 50, 3", 4: "4, 50, 3", 5: "5, 64, 4"}     # K, hidden width, hidden layers
 
 
-def kernel_name(k, counts_digit):
-    """rocprofv3's name of the MFMA scoring kernel of size k: <K, H, NH, FUSE, CLAMP>; FUSE = 3 (TK_MODE_STRONG) when the
-    kernel also counts the leading digit of the combined strategy's selection keys (the default round), CLAMP = false for
-    the shipped networks (pre-activations provably bounded)"""
-    return "score_mfma_kernel<%s, %d, false>" % (KERNEL_SHAPES[k], 3 if counts_digit else 0)
+def kernel_name(k, counts_digit, variant="mfma"):
+    """rocprofv3's name of the scoring kernel of size k that this run launches.  MFMA variant: <K, H, NH, FUSE, CLAMP, J>; FUSE = 3
+    (TK_MODE_STRONG) when the kernel also counts the leading digit of the combined strategy's selection keys (the fused round and the
+    sharded round alike; 0 with --no-fuse-keys), CLAMP = false for the shipped networks (pre-activations provably bounded), J = 2
+    column tiles per pass.  The other variants carry no selection state."""
+    if variant == "valu":
+        return "score_valu_kernel<%s>" % KERNEL_SHAPES[k]
+    if variant == "simple":
+        return "score_simple_kernel<%d>" % k
+    return "score_mfma_kernel<%s, %d, false, 2>" % (KERNEL_SHAPES[k], 3 if counts_digit else 0)
 
 
 CONFIGS = {
@@ -233,7 +238,7 @@ def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     gbs = bytes_per * n_local / (k_ms * 1e-3) / 1e9
     return {"value": n_local / dt, "unit": "candidates/s", "ms_per_step": dt * 1e3, "steps": steps, "strategy": 1,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "eig_only_kernel<%d, true>" % K, "kernel_ms": k_ms,
+                         "traffic": None, "kernel": "eig_only_kernel<%d, true>" % K,      # <largest size class present, counts the selection's leading digit> "kernel_ms": k_ms,
                          "candidates_per_launch": n_local, "bytes_per_candidate": bytes_per,
                          "note": "gather + register Jacobi, no MLP: bound by VALU instruction issue (DESIGN.md section 5), "
                                  "the HBM figure is the algorithmic one"}}
@@ -254,11 +259,11 @@ class _StdoutToStderr(object):
         os.close(self._saved)
 
 
-def roofline(k, n_per_launch, kernel_ms, traffic, counts_digit=True):
+def roofline(k, n_per_launch, kernel_ms, traffic, counts_digit=True, variant="mfma"):
     tflops = FLOPS_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e12
     gbs = BYTES_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e9
     return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-            "traffic": traffic, "kernel": kernel_name(k, counts_digit), "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
+            "traffic": traffic, "kernel": kernel_name(k, counts_digit and variant == "mfma", variant), "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
             "flops_per_candidate": FLOPS_PER_CAND[k], "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
             "bytes_per_candidate": BYTES_PER_CAND[k]}
 
@@ -500,7 +505,7 @@ def main():
                        "bracket": "device point -> host results" if args.device_point else
                                   ("LP point in the handle's pinned buffer (sdpcut_point_buffer) -> host results" if pinned_point
                                    else "host point -> host results")},
-            "roofline": roofline(K, n_local, k_ms, traffic, counts_digit=not args.no_fuse_keys),
+            "roofline": roofline(K, n_local, k_ms, traffic, counts_digit=not args.no_fuse_keys, variant=args.kernel),
         }
         if phases is not None:
             out["phases"] = phases
@@ -526,7 +531,7 @@ def main():
                     st2()
                 torch.cuda.synchronize()
                 d2 = time.perf_counter() - t1
-                r2 = roofline(k2, n_local, float(np.mean(ms2)), None, counts_digit=not args.no_fuse_keys)
+                r2 = roofline(k2, n_local, float(np.mean(ms2)), None, counts_digit=not args.no_fuse_keys, variant=args.kernel)
                 sec["k%d" % k2] = {"value": n_local * n2 / d2, "unit": "candidates/s", "ms_per_step": d2 / n2 * 1e3, "steps": n2,
                                    "kernel_ms": r2["kernel_ms"], "roofline_frac": r2["frac"], "achieved_TFLOPs": r2["achieved"]}
                 s2.close()

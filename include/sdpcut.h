@@ -436,7 +436,11 @@ int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double 
  * on a process-wide default handle (device SDPCUT_COMPAT_DEVICE, default 0) with the built-in
  * networks.  NNs_initialize / NNs_terminate (no-ops in NNs.so) create / destroy that handle; the
  * first neural_net_kD call creates it if needed.  Without a gfx950 device the functions report
- * once on stderr and return NaN -- there is no CPU fallback.
+ * once on stderr and return NaN -- there is no CPU fallback (SURVEY.md section 8 b lists "CPU twins of each"
+ * entry point: deliberately absent).
+ * NOT bit-identical to NNs.so: same operation order, but exp comes from the ROCm device library instead of the
+ * host's libm -- 15-86 % of the outputs (5D ... 2D) agree to the last bit, the rest to 5e-14 (tested to 1e-12 relative against the
+ * values captured from the real NNs.so; profiles/r03_accuracy.txt).
  */
 double neural_net_2D(const double X[5]);
 double neural_net_3D(const double X[9]);

@@ -162,10 +162,12 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
             orig_nxt = A.orig[K][cc];
         }
         eig_tile<K, FUSE>(A, s_cur, out_idx, valid, s_state, s_out, &s_packed[par], tk_hist, c_viol);
-        // the next tile counts into the other word (zero since the barrier of the tile before this one); this tile's is
-        // cleared behind the barrier that ends its use, in front of the barrier of the next tile
-        __syncthreads();
-        if (threadIdx.x == 0) s_packed[par] = 0;
+        if constexpr (SDPCUT_EIG_REPACK && EigPack<K>::CAP > 0) {
+            // the next tile counts into the other word (zero since the barrier of the tile before this one); this tile's is
+            // cleared behind the barrier that ends its use, in front of the barrier of the next tile
+            __syncthreads();
+            if (threadIdx.x == 0) s_packed[par] = 0;
+        }
     }
 }
 

@@ -137,6 +137,7 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         bar_ok = ok;
     }
     __syncthreads();
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                         break;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // pairs with the release in front of the flag (finish_pass)
                 go = ok;
             }
             __syncthreads();
