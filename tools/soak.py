@@ -42,9 +42,13 @@ def main():
             p = int(rng.integers(0, len(points)))
             strat = int(rng.choice([1, 2, 4]))
             sel = int(rng.choice([1, 64, 777, 5000]))
-            sc.set_point(points[p])
-            r = sc.select_round(strat, sel, copy=False)
-            key = (size, p, strat, sel)
+            csr = bool(rng.integers(0, 2))      # (r3) either epilogue: padded rows or the CSR block assembled on the device
+            if csr:
+                r = sc.round_csr(strat, sel, point=points[p])
+            else:
+                sc.set_point(points[p])
+                r = sc.select_round(strat, sel, copy=False)
+            key = (size, p, strat, sel, csr)
             got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
             rounds += 1
             per_kind[key] = per_kind.get(key, 0) + 1
@@ -59,8 +63,9 @@ def main():
                     sys.exit(1)
         if rounds % 2000 < 40:
             print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
-    print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4), every repeat bit-identical"
-          % (rounds, len(first), sizes, len(points)))
+    fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)
+    print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues), every repeat bit-identical; "
+          "%d rounds answered by the path without in-kernel waits" % (rounds, len(first), sizes, len(points), fallbacks))
     sc.close()
 
 
