@@ -1,0 +1,158 @@
+"""CPU-side tests of the round-3 host logic (no GPU): the rank list that carries a fused round's assembled cuts, its
+heads and concatenations, the hand-over to the LP's row store, the build stamp without a compiler, the C-ABI's new
+symbols and struct."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+class _FakeScorer(object):
+    base = 0
+    round_count = 5
+
+    def rank(self, *a, **k):
+        raise AssertionError("the device must not be asked for anything in these tests")
+
+
+def _rank_list(n_head=10, n_total=50, strat=4):
+    """a RankList over a fake binding whose fused round produced cuts for head entries 0, 2, 3, 5, 6, 9 (2, 3 or 5 non-zeros)"""
+    from sdpcutsel_via_nn_amd.cut_solver import RankList, _Binding
+    S = np.array([[i % 7, i % 7 + 1, i % 7 + 2, -1, -1] for i in range(n_total)], dtype=np.int32)
+    ks = np.full(n_total, 3, dtype=np.int32)
+    b = _Binding(_FakeScorer(), None, 12, 78)
+    b.set_arr, b.ks, b.n_at_bind = S, ks, n_total
+    b.point_token = 1
+    vv = np.linspace(0, 1, 90)
+    idx = np.arange(100, 100 + n_head, dtype=np.int64) % n_total
+    score = np.array([1009.0, 1008.0, 1007.0, 1006.0, 1005.0, 0.5, 0.0, -1.0, -2.0, -3.0])[:n_head]
+    row_entry = np.array([0, 2, 3, 5, 6, 9], dtype=np.int32)
+    lens = np.array([2, 3, 5, 2, 3, 5])
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    fused = dict(idx=idx, score=score, lam=-np.ones(n_head), ks=ks[idx], set_inds=S[idx], row_entry=row_entry, indptr=indptr,
+                 indices=np.arange(indptr[-1], dtype=np.int32), values=np.arange(indptr[-1], dtype=np.float64) / 10, rhs=-np.arange(6.0))
+    return RankList(None, b, 1 if strat == 1 else 2, n_total, vv, idx.copy(), score.copy(), strat=strat, sel_size=n_head, fused=fused), b, vv
+
+
+def test_fused_rows_are_a_prefix_of_the_block():
+    rl, b, vv = _rank_list()
+    ptr, ind, val, rhs = rl.fused_rows(10)
+    assert ptr.tolist() == [0, 2, 5, 10, 12, 15, 20] and rhs.tolist() == [-0.0, -1.0, -2.0, -3.0, -4.0, -5.0] and len(ind) == len(val) == 20
+    # the cuts of the first m entries: rows whose head position is < m
+    for m, rows in ((1, 1), (2, 1), (3, 2), (4, 3), (6, 4), (9, 5)):
+        ptr, ind, val, rhs = rl.fused_rows(m)
+        assert rhs.shape[0] == rows and ptr.shape[0] == rows + 1 and len(ind) == ptr[-1]
+    # strong_only (cut_select_qp.py:725-726): stop at the first score <= 0 -> entries 0..5 -> 4 cuts
+    assert rl.fused_rows(10, strong_only=True)[3].shape[0] == 4
+    # another LP point than the one the round ranked at: no fused rows (the same object or equal values are fine)
+    assert rl.fused_rows(10, vars_values=vv) is not None and rl.fused_rows(10, vars_values=vv.copy()) is not None
+    assert rl.fused_rows(10, vars_values=vv + 1e-9) is None
+    # longer than the head, or the scorer has run another round since: no fused rows
+    assert rl.fused_rows(11) is None
+    b.scorer.round_count += 1
+    assert rl.fused_rows(10) is None
+
+
+def test_heads_and_concatenations_keep_the_link_to_the_block():
+    from sdpcutsel_via_nn_amd.cut_solver import RankListHead, _Concat
+    rl, b, vv = _rank_list()
+    head = rl[0:6]
+    assert isinstance(head, RankListHead) and len(head) == 6 and head.parent is rl
+    assert isinstance(head[0:3], RankListHead) and len(head[0:3]) == 3
+    ent = list(head)
+    assert [e[0] for e in ent] == rl.ids(6).tolist() and all(isinstance(e[0], int) and isinstance(e[1], float) for e in ent)
+    assert ent[0][2] == tuple(vv[78 + i] for i in (0, 1, 2))          # curr_pt of candidate 100 % 50 = 0, index set (0, 1, 2)
+    assert head == ent and head[2] == ent[2] and head[1:3] == ent[1:3]
+    # (A + B)[0:sel_size], cut_select_qcqp.py:79, on lists whose heads cover the slice (a slice beyond a head asks the device
+    # for the full ranking -- _FakeScorer.rank raises)
+    first, _, _ = _rank_list(n_total=10)
+    other, _, _ = _rank_list(n_total=10, strat=1)
+    cat = first + other
+    assert isinstance(cat, _Concat) and len(cat) == 20
+    sl = cat[0:13]
+    assert isinstance(sl, _Concat) and len(sl) == 13 and [len(p) for p in sl._parts] == [10, 3]
+    assert isinstance(sl._parts[1], RankListHead) and sl._parts[1].parent is other
+    assert isinstance(cat[0:4]._parts[0], RankListHead)
+    assert len(list(cat[8:12])) == 4
+    with pytest.raises(AssertionError, match="device"):
+        rl[0:11]
+
+
+def test_assembled_cuts_reach_both_kinds_of_row_store():
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import GpuCutSelectionMixin
+    rl, b, vv = _rank_list()
+
+    class Solver(GpuCutSelectionMixin):
+        pass
+    s = Solver()
+    s._my_prob = harness.LinearRelaxation(np.zeros(90))
+    nb = s._gen_eigcuts_selected(4, 6, rl, vars_values=vv)
+    store = s._my_prob.linear_constraints
+    assert nb == 4 == store.get_num() and store.senses == ["G"] * 4 and store.rhs == [-0.0, -1.0, -2.0, -3.0]
+    assert [r.ind for r in store.rows] == [[0, 1], [2, 3, 4], [5, 6, 7, 8, 9], [10, 11]]
+    # the store owns copies: the pinned block is reused by the next round
+    rl._fused["values"][:] = -7.0
+    assert store.rows[0].val == [0.0, 0.1]
+
+    class RefStore(object):                          # the reference's LP surface (cplex): add(lin_expr=, rhs=, senses=) only
+        def __init__(self):
+            self.calls = []
+
+        def add(self, lin_expr=(), rhs=(), senses=()):
+            self.calls.append((list(lin_expr), list(rhs), list(senses)))
+
+    class Prob(object):
+        linear_constraints = RefStore()
+    rl2, _, vv2 = _rank_list()
+    s2 = Solver()
+    s2._sparse_pair = harness.SparsePair
+    s2._my_prob = Prob()
+    assert s2._gen_eigcuts_selected(4, 10, rl2[0:10], strong_only=True, vars_values=vv2) == 4
+    (rows, rhs, senses), = Prob.linear_constraints.calls
+    assert [r.ind for r in rows] == [[0, 1], [2, 3, 4], [5, 6, 7, 8, 9], [10, 11]] and rhs == [-0.0, -1.0, -2.0, -3.0] and senses == ["G"] * 4
+    assert all(isinstance(v, float) for r in rows for v in r.val) and all(isinstance(i, int) for r in rows for i in r.ind)
+
+
+def test_build_without_a_compiler_uses_a_matching_shipped_library(monkeypatch, tmp_path):
+    from sdpcutsel_via_nn_amd import build
+    build.build(verbose=False)
+    monkeypatch.setattr(build, "HIPCC", str(tmp_path / "no-such-hipcc"))
+    assert build._compiler_id().startswith("unavailable")
+    assert build.build(verbose=False) == build.LIB           # sources match the stamp: the shipped library is the answer
+    src = os.path.join(build.CSRC, "shard.hip")
+    text = open(src).read()
+    try:
+        with open(src, "a") as f:
+            f.write("\n// changed\n")
+        with pytest.raises(RuntimeError, match="no hipcc"):
+            build.build(verbose=False)
+    finally:
+        with open(src, "w") as f:
+            f.write(text)
+    monkeypatch.undo()
+    build.build(verbose=False)                                # (nothing is stale: no compiler run either)
+
+
+def test_round_csr_struct_matches_the_header():
+    """sdpcut_round_csr_t as ctypes sees it == as a C compiler sees the header"""
+    import subprocess
+    from sdpcutsel_via_nn_amd import _capi
+    src = tmp = os.path.join(ROOT, "tests", "_csr_layout.c")
+    exe = os.path.join(ROOT, "tests", "_csr_layout")
+    fields = [f[0] for f in _capi.RoundCsr._fields_]
+    with open(src, "w") as f:
+        f.write('#include <stdio.h>\n#include <stddef.h>\n#include "../include/sdpcut.h"\nint main(void) { printf("%zu", sizeof(sdpcut_round_csr_t));\n'
+                + "".join('printf(" %%zu", offsetof(sdpcut_round_csr_t, %s));\n' % n for n in fields) + "return 0; }\n")
+    try:
+        subprocess.check_call(["gcc", "-o", exe, src])
+        out = [int(v) for v in subprocess.check_output([exe]).split()]
+    finally:
+        for p in (src, exe):
+            if os.path.exists(p):
+                os.remove(p)
+    assert out[0] == ctypes.sizeof(_capi.RoundCsr)
+    assert out[1:] == [getattr(_capi.RoundCsr, n).offset for n in fields]
