@@ -249,6 +249,50 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// v + v(lane ^ 32) and v + v(lane ^ 16) through v_permlane{32,16}_swap_b32 (gfx950) instead of ds_bpermute_b32: the swap of
+// a register pair holding the same value leaves one register with the lower / even rows' values everywhere and the other with the
+// upper / odd rows', and their sum is the butterfly sum on every lane -- bit for bit what v + __shfl_xor(v, 32 | 16) gives
+// (addition commutes).  No LDS crossbar round trip (two dependent ones per reduction, ~250 cycles, at every layer boundary of a pass).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#ifndef SDPCUT_PERMLANE_SWAP
+#define SDPCUT_PERMLANE_SWAP 1
+#endif
+__device__ __forceinline__ double xor_add32(double v)
+{
+#if SDPCUT_PERMLANE_SWAP
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+#else
+    return v + __shfl_xor(v, 32);
+#endif
+}
+__device__ __forceinline__ double xor_add16(double v)
+{
+#if SDPCUT_PERMLANE_SWAP
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u32x2 b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+#else
+    return v + __shfl_xor(v, 16);
+#endif
+}
+// v(lane ^ 32)
+__device__ __forceinline__ double xor_get32(double v, int lane)
+{
+#if SDPCUT_PERMLANE_SWAP
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);      // [0]: lower half everywhere, [1]: upper half everywhere
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double lower = __hiloint2double((int)b[0], (int)a[0]), upper = __hiloint2double((int)b[1], (int)a[1]);
+    return (lane & 32) ? lower : upper;
+#else
+    return __shfl_xor(v, 32);
+#endif
+}
+
 // Tail rows of a hidden layer on the VALU: ts[u] holds this lane's partial dot product of tail
 // neuron u over the k-slots it owns (n = 4 s + q); the four k-slot lanes of a candidate column
 // (lane, lane^16, lane^32, lane^48) are summed, and lane q keeps neuron u = q in register 0 of
@@ -267,12 +311,12 @@ __device__ __forceinline__ void tail_rows2(const double (&ts)[2][NT ? NT : 1], c
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             double v = ts[j][u];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v = xor_add16(v);
+            v = xor_add32(v);
             pre = (q == 2 * j + u) ? v + bias[u] : pre;
         }
     const double t = tansig_y8<CLAMP>(pre);
-    const double t1 = __shfl_xor(t, 32);
+    const double t1 = xor_get32(t, 16 * q);
     out0 = d4{0.0, 0.0, 0.0, 0.0};
     out1 = d4{0.0, 0.0, 0.0, 0.0};
     out0[0] = (q < NT) ? t : 0.0;
@@ -289,8 +333,8 @@ __device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], c
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         double v = ts[0][u];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
+        v = xor_add16(v);
+        v = xor_add32(v);
         pre = (q == u) ? v + bias[u] : pre;
     }
     const double t = tansig_y8<CLAMP>(pre);
@@ -672,8 +716,8 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (16 * t + 4 * r < H) part = fma(cur[t][j][r], WOUT_AT(16 * t + 4 * r + q), part);
-                part += __shfl_xor(part, 16);
-                part += __shfl_xor(part, 32);
+                part = xor_add16(part);
+                part = xor_add32(part);
                 if (q == 0) ynn[wave][16 * J * pass + 16 * j + c16] = part;
             }
         }
