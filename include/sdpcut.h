@@ -351,8 +351,11 @@ int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int6
  * caller sums them); entries beyond the summed list length are pads.
  */
 int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t count, void *d_record);
+/* pitch_words: distance between the records of consecutive ranks in d_allrec, in int64 words (0 = the record's own length:
+ * one list per gathered buffer); larger when the records of several lists travel in one all-gather (the QCQP round's two
+ * covers: d_allrec then points at this list's record of rank 0 inside the buffer). */
 int sdpcut_shard_finish_enqueue(sdpcut_handle h, int32_t world, int64_t count, int32_t fields, const void *d_allrec,
-                                int64_t sel_size, int32_t coef_ld);
+                                int64_t pitch_words, int64_t sel_size, int32_t coef_ld);
 /* compact_own != 0: block as sdpcut_shard_finish_round_own, *n_own = rows of this shard; 0: as sdpcut_shard_finish_round_view */
 int sdpcut_shard_finish_wait(sdpcut_handle h, int32_t compact_own, const void **block, int64_t *n_own);
 int sdpcut_shard_finish_round(sdpcut_handle h, int32_t world, int64_t count,

@@ -70,7 +70,7 @@ SIGNATURES = {
     "sdpcut_round_view": [_vp, _dp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_round_csr": [_vp, _dp, _c.c_int, _c.c_int64, _c.POINTER(RoundCsr)],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
-    "sdpcut_shard_finish_enqueue": [_vp, _c.c_int32, _c.c_int64, _c.c_int32, _vp, _c.c_int64, _c.c_int32],
+    "sdpcut_shard_finish_enqueue": [_vp, _c.c_int32, _c.c_int64, _c.c_int32, _vp, _c.c_int64, _c.c_int64, _c.c_int32],
     "sdpcut_shard_finish_wait": [_vp, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p],
     "sdpcut_shard_finish_round": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _i64p, _i64p, _dp, _dp, _dp, _dp, _i32p],
     "sdpcut_shard_finish_round_view": [_vp, _c.c_int32, _c.c_int64, _vp, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p)],
@@ -486,13 +486,14 @@ class Scorer(object):
             self._shard_view_key = key
         return self._shard_views_cache
 
-    def shard_finish_enqueue(self, world, count, d_allrec_ptr, sel_size, fields=2):
+    def shard_finish_enqueue(self, world, count, d_allrec_ptr, sel_size, fields=2, pitch_words=0):
         """second half of a sharded round, enqueued without host synchronisation (sdpcut_shard_finish_enqueue);
-        fields = 3: the records carry obj_improve as secondary key (SDPCUT_PART_COMBALL)"""
+        fields = 3: the records carry obj_improve as secondary key (SDPCUT_PART_COMBALL); pitch_words: distance between
+        consecutive ranks' records when several lists share the gathered buffer (0 = one list per buffer)"""
         self.round_count += 1
         self._shard_pending = (int(world), int(sel_size), self.row_len)
         self._check(self._lib.sdpcut_shard_finish_enqueue(self._h, int(world), int(count), int(fields), _vp(d_allrec_ptr),
-                                                          int(sel_size), self.row_len))
+                                                          int(pitch_words), int(sel_size), self.row_len))
 
     def shard_finish_wait(self, own=True):
         """-> dict(headers, idx, score, lam, coef, rhs, ks[, pos, n_own]): views of the handle's pinned block, which the

@@ -50,11 +50,12 @@ __global__ void shard_secondary_kernel(int64_t count, const int64_t *d_c4, const
 // across ranks and are ordered by rank, which keeps the positions a permutation.
 // fields = 2: [scores | ids]; 3: [scores | ids | secondary] (the combined strategy with every entry visited:
 // equal new scores keep obj_improve order, the second stable sort of :625 under the first of :601).
-__global__ void shard_mergerank_kernel(int world, int64_t count, int fields, const int64_t *allrec, int64_t sel, double *scores,
+// rl = distance between the records of consecutive ranks in words (>= 8 + fields * count: several lists' records may share one
+// gathered buffer, the QCQP round's two covers travel in ONE all-gather)
+__global__ void shard_mergerank_kernel(int world, int64_t count, int fields, int64_t rl, const int64_t *allrec, int64_t sel, double *scores,
                                        int64_t *ids, int64_t *headers)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t rl = SHARD_HDR + fields * count;
     if (i < (int64_t)world * SHARD_HDR) headers[i] = allrec[(i / SHARD_HDR) * rl + (i % SHARD_HDR)];
     if (i >= (int64_t)world * count) return;
     const int r = (int)(i / count);
@@ -147,10 +148,13 @@ extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t coun
 // sdpcut_shard_finish_wait collects it.  (Two lists per round -- the QCQP composition -- enqueue both halves
 // before the first wait: one host wait per round.)
 extern "C" int sdpcut_shard_finish_enqueue(sdpcut_handle h, int32_t world, int64_t count, int32_t fields, const void *d_allrec,
-                                           int64_t sel_size, int32_t coef_ld)
+                                           int64_t pitch_words, int64_t sel_size, int32_t coef_ld)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || (fields != 2 && fields != 3))
+    const int64_t rl = SHARD_HDR + (int64_t)fields * count;
+    if (pitch_words == 0) pitch_words = rl;
+    if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || (fields != 2 && fields != 3) ||
+        pitch_words < rl)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish arguments");
     if (sel_size > 16384) return sdpcut_fail(h, SDPCUT_EINVAL, "shard_finish: at most 16384 entries");
     if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD) return sdpcut_fail(h, SDPCUT_EINVAL, "bad coef_ld");
@@ -168,7 +172,7 @@ extern "C" int sdpcut_shard_finish_enqueue(sdpcut_handle h, int32_t world, int64
     double *d_ms = (double *)(d_mi + s);
     const size_t nthr = tot > (size_t)world * SHARD_HDR ? tot : (size_t)world * SHARD_HDR;
     hipLaunchKernelGGL(shard_mergerank_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, h->stream, (int)world,
-                       count, (int)fields, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, (int64_t *)h->pinned_dev);
+                       count, (int)fields, pitch_words, (const int64_t *)d_allrec, sel_size, d_ms, d_mi, (int64_t *)h->pinned_dev);
     // rows of the merged head that live on this shard (the others are marked ks = 0, lam = NaN),
     // stored -- with the merged ids and scores -- straight into the host block
     // (completion: the rows kernel's last workgroup stores the round's serial number into word 7 of the
@@ -221,7 +225,7 @@ extern "C" int sdpcut_shard_finish_wait(sdpcut_handle h, int32_t compact_own, co
 extern "C" int sdpcut_shard_finish_round_view(sdpcut_handle h, int32_t world, int64_t count, const void *d_allrec,
                                               int64_t sel_size, int32_t coef_ld, const void **block)
 {
-    int rc = sdpcut_shard_finish_enqueue(h, world, count, 2, d_allrec, sel_size, coef_ld);
+    int rc = sdpcut_shard_finish_enqueue(h, world, count, 2, d_allrec, 0, sel_size, coef_ld);
     if (rc) return rc;
     return sdpcut_shard_finish_wait(h, 0, block, nullptr);
 }
@@ -231,7 +235,7 @@ extern "C" int sdpcut_shard_finish_round_own(sdpcut_handle h, int32_t world, int
 {
     if (!h) return SDPCUT_EINVAL;
     if (!n_own) return sdpcut_fail(h, SDPCUT_EINVAL, "bad shard_finish_round arguments");
-    int rc = sdpcut_shard_finish_enqueue(h, world, count, 2, d_allrec, sel_size, coef_ld);
+    int rc = sdpcut_shard_finish_enqueue(h, world, count, 2, d_allrec, 0, sel_size, coef_ld);
     if (rc) return rc;
     return sdpcut_shard_finish_wait(h, 1, block, n_own);
 }

@@ -665,7 +665,7 @@ class GpuCutSelectionMixin(object):
         r = rhs.shape[0]
         store = self._my_prob.linear_constraints
         if hasattr(store, "add_csr"):
-            store.add_csr(np.array(indptr, dtype=np.int64), np.array(ind, dtype=np.int64), np.array(val), np.array(rhs), "G")
+            store.add_csr(np.array(indptr), np.array(ind), np.array(val), np.array(rhs), "G")      # (int32 index arrays as the device wrote them)
             return r
         ptr, ind, val = indptr.tolist(), ind.tolist(), val.tolist()
         rows = [pair(ind=ind[ptr[c]:ptr[c + 1]], val=val[ptr[c]:ptr[c + 1]]) for c in range(r)]

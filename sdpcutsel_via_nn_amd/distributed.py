@@ -64,19 +64,23 @@ class DeviceOps(object):
     # -- fused round (sdpcut_shard_head_device / sdpcut_shard_finish_enqueue / _wait) ----------------
     max_head = 16384
 
-    def shard_head(self, strat, count):
+    def shard_head(self, strat, count, into=None):
         """packed head record of this shard, enqueued on the current stream (no host sync); strat
-        _capi.PART_COMBALL: three fields per entry (new score, id, obj_improve), else two"""
+        _capi.PART_COMBALL: three fields per entry (new score, id, obj_improve), else two.  into: an int64 device
+        tensor of the record's length to write it to (part of a buffer several lists share)"""
         fields = 3 if strat == _capi.PART_COMBALL else 2
-        rec = self._rec.get((count, fields))           # one buffer per record shape, reused every round
+        rec = into
         if rec is None:
-            rec = self._rec[(count, fields)] = torch.empty(8 + fields * count, dtype=torch.int64, device=self.device)
+            rec = self._rec.get((count, fields))           # one buffer per record shape, reused every round
+            if rec is None:
+                rec = self._rec[(count, fields)] = torch.empty(8 + fields * count, dtype=torch.int64, device=self.device)
         self.scorer.shard_head_device(strat, count, rec.data_ptr())
         return rec
 
-    def shard_finish_enqueue(self, world, count, allrec, sel_size, fields=2):
-        """merge of the gathered records + rows of the own entries, enqueued (no host sync)"""
-        self.scorer.shard_finish_enqueue(world, count, allrec.data_ptr(), sel_size, fields)
+    def shard_finish_enqueue(self, world, count, allrec, sel_size, fields=2, pitch_words=0, offset_words=0):
+        """merge of the gathered records + rows of the own entries, enqueued (no host sync); pitch / offset: this list's
+        records inside a gathered buffer that several lists share"""
+        self.scorer.shard_finish_enqueue(world, count, allrec.data_ptr() + 8 * int(offset_words), sel_size, fields, pitch_words)
 
     def shard_finish_wait(self):
         """-> dict(headers, idx, score, lam, coef, rhs, ks, pos, n_own): the round's one host wait"""
@@ -238,15 +242,28 @@ class ShardedSelector(object):
     def begin_round(self, strat, sel_size):
         """First part of :meth:`select_round`, up to and including the enqueued merge + rows: no host wait.
         -> token for :meth:`end_round`.  Two selectors (the two covers of a QCQP round) may both begin before either ends."""
+        token = self.begin_head(strat, sel_size)
+        if token[3]:
+            self.finish_enqueue(token, self._all_gather(token[4]))
+        return token[:4]
+
+    def begin_head(self, strat, sel_size, into=None):
+        """only the shard's packed head (into = a slice of a buffer shared with other lists) -> token incl. the record;
+        the caller all-gathers and calls :meth:`finish_enqueue`"""
         if strat not in (1, 2, 4):
             raise ValueError("strategy must be 1, 2 or 4")
         sel = min(int(sel_size), self.n_global)
         ops = self.ops
         fused = 1 <= sel <= getattr(ops, "max_head", 0) and hasattr(ops, "shard_finish_enqueue")
-        if fused:
-            rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel)
-            ops.shard_finish_enqueue(self.world, sel, self._all_gather(rec), sel)
-        return (strat, sel_size, sel, fused)
+        rec = ops.shard_head(_capi.PART_STRONG if strat == 4 else strat, sel, into=into) if fused else None
+        return (strat, sel_size, sel, fused, rec)
+
+    def finish_enqueue(self, token, allrec, pitch_words=0, offset_words=0):
+        self.ops.shard_finish_enqueue(self.world, token[2], allrec, token[2], pitch_words=pitch_words, offset_words=offset_words)
+
+    @staticmethod
+    def record_words(sel):
+        return 8 + 2 * int(sel)
 
     def _unpack(self, out, strat, sel, length, cnt, copy, big_m):
         valid = min(sel, length)
@@ -320,6 +337,7 @@ class ShardedQCQPRound(object):
 
     def __init__(self, sel_obj, sel_cons):
         self.sel_obj, self.sel_cons = sel_obj, sel_cons
+        self._buf = {}
 
     def round(self, strat, sel_size, vars_values):
         """-> dict(new_strat, is_obj bool[w], ids int64[w] (global position in the cover the entry
@@ -335,12 +353,33 @@ class ShardedQCQPRound(object):
         # the length of A's list (:79); under strategies 2 / 4 that is the objective cover's size, known beforehand,
         # under strategy 1 the number of its violated candidates: B is then asked for sel_size and trimmed.
         rest_bound = sel_size - (min(so.n_global, sel_size) if (have_a and strat != 1) else 0)
+        want_b = rest_bound > 0 and sc is not None and sc.n_global > 0
         if have_a:
             so.ops.scorer.set_point(vars_values)
-            ta = so.begin_round(strat, sel_size)
-        if rest_bound > 0 and sc is not None and sc.n_global > 0:
+        if want_b:
             sc.ops.scorer.set_point(vars_values)
-            tb = sc.begin_round(1, rest_bound)
+        sel_a = min(sel_size, so.n_global) if have_a else 0
+        sel_b = min(rest_bound, sc.n_global) if want_b else 0
+        one_buffer = (have_a and want_b and 1 <= sel_a <= getattr(so.ops, "max_head", 0) and 1 <= sel_b <= getattr(sc.ops, "max_head", 0)
+                      and hasattr(so.ops, "shard_finish_enqueue") and so.world == sc.world and so.group is sc.group
+                      and getattr(so.ops, "device", None) == getattr(sc.ops, "device", None))
+        if one_buffer:
+            # ONE all-gather for the round: the two covers' records side by side in one buffer (these messages are latency-bound)
+            la, lb = so.record_words(sel_a), sc.record_words(sel_b)
+            buf = self._buf.get((la, lb))
+            if buf is None:
+                buf = self._buf[(la, lb)] = torch.empty(la + lb, dtype=torch.int64, device=so.ops.device)
+            ta = so.begin_head(strat, sel_size, into=buf[:la])
+            tb = sc.begin_head(1, rest_bound, into=buf[la:])
+            allrec = so._all_gather(buf)
+            so.finish_enqueue(ta, allrec, pitch_words=la + lb, offset_words=0)
+            sc.finish_enqueue(tb, allrec, pitch_words=la + lb, offset_words=la)
+            ta, tb = ta[:4], tb[:4]
+        else:
+            if have_a:
+                ta = so.begin_round(strat, sel_size)
+            if want_b:
+                tb = sc.begin_round(1, rest_bound)
         if ta is not None:
             a = so.end_round(ta)
             n_obj = len(a["ids"])                        # min(len(comb_obj), sel_size), :79

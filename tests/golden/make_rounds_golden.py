@@ -26,7 +26,7 @@ import make_golden  # noqa: E402
 from make_golden import REF, ROOT, _Recorder, harness  # noqa: E402
 
 
-def main(name, dim, strat, rounds, frac=0.1):
+def main(name, dim, strat, rounds, frac=0.1, out_dir=HERE):
     qp, _ = make_golden.import_reference()
     cs = qp.CutSolver()
     cs._dim = dim
@@ -80,9 +80,10 @@ def main(name, dim, strat, rounds, frac=0.1):
               % (r, cur, nxt, nb_cuts, t_sep, time.time() - t, -out["bounds"][-1]), flush=True)
         cur = nxt
         out["rounds_done"] = np.int64(r)
-        np.savez_compressed(os.path.join(HERE, "rounds_%s_d%d_s%d.npz" % (name.replace("-", "_"), dim, strat)),
+        np.savez_compressed(os.path.join(out_dir, "rounds_%s_d%d_s%d.npz" % (name.replace("-", "_"), dim, strat)),
                             **{k: (np.array(v) if isinstance(v, list) else v) for k, v in out.items()})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    # optional 5th argument: directory to write to (long captures write aside and are moved in when complete)
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), out_dir=sys.argv[5] if len(sys.argv) > 5 else HERE)

@@ -188,7 +188,13 @@ class FakeOps(object):
         return scores[o], ids[o]
     # fused round: packed record / merge + rows of the own entries (row = the candidate's lam only)
     max_head = 16384
-    def shard_head(self, strat, count):
+    def shard_head(self, strat, count, into=None):
+        rec = self._shard_head(strat, count)
+        if into is not None:
+            into.copy_(rec)
+            return into
+        return rec
+    def _shard_head(self, strat, count):
         n = self.obj.shape[0]
         nviol, npos = int((self.lam < oracle.THRES_NEG_EIGVAL).sum()), int((self.obj > 0).sum())
         if strat == _capi.PART_COMBALL:      # PART_COMBALL: every entry visited -> the shard's own combined ranking, obj_improve as third field
@@ -208,8 +214,11 @@ class FakeOps(object):
         mine = (ids >= self.base) & (ids < self.base + n)
         c = int(mine.sum())
         return mine, self.lam[ids[mine] - self.base], np.zeros((c, 9)), np.zeros(c), np.full(c, 3, dtype=np.int32)
-    def shard_finish_enqueue(self, world, count, allrec, sel, fields=2):
+    def shard_finish_enqueue(self, world, count, allrec, sel, fields=2, pitch_words=0, offset_words=0):
         a = allrec.view(world, -1).numpy()
+        if pitch_words:
+            assert a.shape[1] == pitch_words
+            a = a[:, offset_words:offset_words + 8 + fields * count]
         s = np.ascontiguousarray(a[:, 8:8 + count]).reshape(-1).view(np.float64)
         i = np.ascontiguousarray(a[:, 8 + count:8 + 2 * count]).reshape(-1)
         if fields == 3:
