@@ -214,6 +214,55 @@ def bench_c3(device_index, steps, warm=20):
     return out
 
 
+# ----------------------------------------------------------------------------- c5: the QCQP round (BASELINE configs[4]) on one GPU
+C5_INSTANCE, C5_DIM = "q_50_10_25_1", 5
+
+
+def bench_c5(device_index, steps, warm=10):
+    """ms per QCQP separation round (cut_select_qcqp.py:64-98) on q_50_10_25_1 with 5-variable sub-problems: both covers and
+    their intersection built on the device (4 + 1 377 077 candidates), the LP point of the round the reference itself ran
+    (tests/golden/inst_qcqp50.npz), CutSolverQCQP.select_and_generate_round -- objective cover by the strategy, constraints-only
+    cover by feasibility, (A + B)[0:5000], cuts handed to the LP's row store."""
+    import torch
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolverQCQP, DeviceAgg
+    gold = os.path.join(ROOT, "tests", "golden")
+    inst = harness.parse_osil(os.path.join(gold, "instances", C5_INSTANCE + ".osil"))
+    vv = np.ascontiguousarray(np.load(os.path.join(gold, "inst_qcqp50.npz"))["vars"], dtype=np.float64)
+    n = inst["nb_vars"]
+    cs = CutSolverQCQP(device_index)
+    cs._dim, cs._nb_vars, cs._nb_lifted, cs._Q_arr = C5_DIM, n, inst["nb_lifted"], inst["Q_arr"]
+    cs._load_neural_nets()
+    t0 = time.perf_counter()
+    sc_o, sc_c = cs._gpu_new_scorer(), cs._gpu_new_scorer()
+    for sc in (sc_o, sc_c):
+        sc.set_instance(n, np.asarray(inst["Q_arr"], dtype=np.float64))
+    n_o, n_c = sc_o.set_candidates_cover_split(sc_c, inst["adj"], inst["adj_cons"], C5_DIM)
+    t_cover = time.perf_counter() - t0
+    cover_obj, cover_cons = DeviceAgg(sc_o, n_o, n, inst["Q_arr"]), DeviceAgg(sc_c, n_c, n, inst["Q_arr"])
+    cs._agg_list = cover_obj
+    cs._my_prob = harness.LinearRelaxation(np.zeros(inst["nb_lifted"] + n))
+    out = {"instance": "%s, %d-variable sub-problems: objective cover %d, constraints-only cover %d candidates (both built and "
+                       "intersected on the device in %.0f ms incl. handle set-up)" % (C5_INSTANCE, C5_DIM, n_o, n_c, t_cover * 1e3),
+           "sel_size": SEL, "steps": steps}
+    for strat in (4, 1):
+        def one():
+            cs._my_prob.linear_constraints = harness._RowStore()
+            return cs.select_and_generate_round(strat, vv, 1, SEL, cover_obj, cover_cons)
+        for _ in range(warm):
+            r = one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out["strategy_%d" % strat] = {"round_ms": ms, "cuts": r[2], "candidates_per_s": (n_o + n_c) / (ms * 1e-3)}
+    sc_o.close()
+    sc_c.close()
+    return out
+
+
 def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     """the feasibility round (strategy 1) on the main workload: eigenvalue-only kernel + selection + rows"""
     import torch
@@ -274,7 +323,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2")
-    ap.add_argument("--no-c3", action="store_true", help="skip secondary.c3 (the spar125-075-1 dim-4 rounds) of the default run")
+    ap.add_argument("--no-c3", action="store_true", help="skip secondary.c3 / c5 (the spar125-075-1 dim-4 rounds, the q_50 QCQP round) of the default run")
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the k = 2, 4, 5 single-GPU rates")
@@ -540,6 +589,7 @@ def main():
             out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
+                out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))
         if world == 1 and not args.no_cpu_baseline:
             vv_host = np.array(vv_host)     # (detach from the handle's pinned buffer: worker processes pickle it)
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample

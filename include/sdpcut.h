@@ -326,6 +326,12 @@ typedef struct sdpcut_round_csr {
     const double *rhs;
 } sdpcut_round_csr_t;
 int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, sdpcut_round_csr_t *out);
+/* The same in two halves: _begin enqueues the whole round and returns without waiting, _end waits and fills *out (and runs the
+ * general ranking path itself in the rare cases the enqueued selection is not the answer).  A handle holds one pending round;
+ * DIFFERENT handles may all begin before any ends -- their device work overlaps.  The QCQP round ranks two lists per LP point
+ * (cut_select_qcqp.py:64-78): begin(objective cover), begin(constraints cover), end, end. */
+int sdpcut_round_csr_begin(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size);
+int sdpcut_round_csr_end(sdpcut_handle h, sdpcut_round_csr_t *out);
 
 /*
  * The same round over candidate shards (one handle per GPU, SURVEY 8 e): the two device-side

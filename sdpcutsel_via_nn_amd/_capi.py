@@ -69,6 +69,8 @@ SIGNATURES = {
     "sdpcut_select_round_view": [_vp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_round_view": [_vp, _dp, _c.c_int, _c.c_int64, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p, _i64p, _i64p, _i32p, _i64p],
     "sdpcut_round_csr": [_vp, _dp, _c.c_int, _c.c_int64, _c.POINTER(RoundCsr)],
+    "sdpcut_round_csr_begin": [_vp, _dp, _c.c_int, _c.c_int64],
+    "sdpcut_round_csr_end": [_vp, _c.POINTER(RoundCsr)],
     "sdpcut_shard_head_device": [_vp, _c.c_int, _c.c_int64, _vp],
     "sdpcut_shard_finish_enqueue": [_vp, _c.c_int32, _c.c_int64, _c.c_int32, _vp, _c.c_int64, _c.c_int64, _c.c_int32],
     "sdpcut_shard_finish_wait": [_vp, _c.c_int32, _c.POINTER(_c.c_void_p), _i64p],
@@ -420,17 +422,41 @@ class Scorer(object):
         row_entry, indptr, indices, values, rhs).  The arrays are numpy views of the handle's pinned host block (written
         by the device, valid until the next call on this Scorer); copy=True detaches them.  point=None keeps the
         current LP point."""
-        vv = None
-        if point is not None:
-            vv = _f64(point)
-            n = self.nb_vars
-            if vv.shape != (n * (n + 1) // 2 + n,):
-                raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
+        vv = self._csr_point(point)
         self.round_count += 1
+        out = self._csr_out()
+        self._check(self._lib.sdpcut_round_csr(self._h, _ptr(vv, _dp), int(strat), int(sel_size), ctypes.byref(out)))
+        return self._csr_unpack(out, copy)
+
+    def round_csr_begin(self, strat, sel_size, point=None):
+        """First half of round_csr (sdpcut_round_csr_begin): enqueue the whole round, do not wait.  Several Scorers may begin
+        before any ends; their device work overlaps."""
+        vv = self._csr_point(point)
+        self.round_count += 1
+        self._check(self._lib.sdpcut_round_csr_begin(self._h, _ptr(vv, _dp), int(strat), int(sel_size)))
+
+    def round_csr_end(self, copy=False):
+        """Second half of round_csr (sdpcut_round_csr_end): wait for the round begun on this Scorer; the same dict."""
+        out = self._csr_out()
+        self._check(self._lib.sdpcut_round_csr_end(self._h, ctypes.byref(out)))
+        return self._csr_unpack(out, copy)
+
+    def _csr_point(self, point):
+        if point is None:
+            return None
+        vv = _f64(point)
+        n = self.nb_vars
+        if vv.shape != (n * (n + 1) // 2 + n,):
+            raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
+        return vv
+
+    def _csr_out(self):
         out = getattr(self, "_csr_struct", None)
         if out is None:
             out = self._csr_struct = RoundCsr()
-        self._check(self._lib.sdpcut_round_csr(self._h, _ptr(vv, _dp), int(strat), int(sel_size), ctypes.byref(out)))
+        return out
+
+    def _csr_unpack(self, out, copy):
         c, w, r = int(out.cap), int(out.n_out), int(out.n_rows)
         if c and out.idx:
             key = (out.idx, c, int(out.row_ld))

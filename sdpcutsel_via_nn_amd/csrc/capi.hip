@@ -519,6 +519,7 @@ int sdpcut_point_buffer(sdpcut_handle h, double **buf)
 int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
 {
     if (!h) return SDPCUT_EINVAL;
+    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
     if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "vars_values is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -551,6 +552,7 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
 int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
 {
     if (!h) return SDPCUT_EINVAL;
+    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
     if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!d_vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "d_vars_values is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -565,6 +567,7 @@ int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
 int sdpcut_score(sdpcut_handle h, uint32_t flags)
 {
     if (!h) return SDPCUT_EINVAL;
+    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
     if (!(flags & (SDPCUT_EIG | SDPCUT_NN)) || (flags & ~(uint32_t)(SDPCUT_EIG | SDPCUT_NN)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "flags must be a combination of SDPCUT_EIG and SDPCUT_NN");
     if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
@@ -624,6 +627,7 @@ int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, i
                 int64_t *n_total, int32_t *new_strat, int64_t *counters)
 {
     if (!h) return SDPCUT_EINVAL;
+    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
     if (max_out < 0 || (max_out > 0 && (!idx_out || !score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
     HIP_TRY(h, hipSetDevice(h->device));
     int64_t cap = max_out < h->N ? max_out : h->N;
@@ -721,17 +725,20 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
 
 } // extern "C"
 
-// One fused round: score (if needed) -> rank -> epilogue.  csr = false: padded rows, block layout of
-// sdpcut_select_round_view; csr = true: the CSR block of sdpcut_round_csr (rows.hip, csr_layout).
-static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_ld, bool csr, const void **block,
-                      int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
+// One fused round in two halves: round_begin enqueues everything -- score (if needed) -> rank -> epilogue into the pinned block --
+// WITHOUT waiting; round_end waits, reads the counters and, when the enqueued selection is not the answer (a void one; the
+// combined scan of heads > 8192), runs the general path.  csr = false: padded rows, block layout of sdpcut_select_round_view;
+// csr = true: the CSR block of sdpcut_round_csr (rows.hip, csr_layout).  Two handles may both begin before either ends: their
+// device work overlaps (the QCQP round's two covers).
+static int round_begin(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_ld, bool csr)
 {
     if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_STRAT_COMB)
         return sdpcut_fail(h, SDPCUT_EINVAL, "strategy must be 1 (feasibility), 2 (optimality) or 4 (combined)");
-    if (sel_size < 0 || !block || !cap_out || !n_out) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    if (sel_size < 0) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
     if (!h->have_point || !h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
     if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD)
         return sdpcut_fail(h, SDPCUT_EINVAL, "coef_ld must hold the longest row (k + k(k+1)/2) and be <= SDPCUT_ROW_LD");
+    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round is already pending on this handle: end it first");
     HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
                           : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
@@ -741,11 +748,13 @@ static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_l
     bool auto_regime = false;
     rc = score_for_selection(h, strat, sel_size, cap, need, h->auto_regime, &stage, &auto_regime);
     if (rc) return rc;
-    *n_out = 0;
-    *cap_out = cap;
-    *block = nullptr;
-    if (cap == 0)   // nothing to generate; still report the ranking's length / strategy switch
-        return sdpcut_rank(h, strat, sel_size, 0, nullptr, nullptr, n_total, new_strat, counters);
+    PendingRound &P = h->pend;
+    P = PendingRound();
+    P.strat = strat; P.sel_size = sel_size; P.cap = cap; P.ld = coef_ld; P.csr = csr;
+    if (cap == 0) {   // nothing to generate; round_end still reports the ranking's length / strategy switch
+        P.active = true;
+        return SDPCUT_OK;
+    }
     // one block for everything a round returns: counters | idx | score | lam | rhs | coef | ks
     const size_t c = (size_t)cap;
     const size_t ret_bytes = csr ? csr_layout(cap, coef_ld).bytes : 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4;
@@ -753,6 +762,47 @@ static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_l
     if (rc) return rc;
     rc = ensure_pinned(h, ret_bytes);
     if (rc) return rc;
+    int64_t *d_idx = (int64_t *)((char *)h->d_stage + 64);
+    double *d_sc = (double *)(d_idx + c);
+    if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    int64_t *hdr = (int64_t *)h->pinned;
+    if (csr) hdr[8] = hdr[9] = hdr[10] = 0;
+    // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
+    // results directly into the pinned host block (no copy engine); one synchronisation
+    const int64_t *d_cnt = nullptr;
+    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, stage, auto_regime);
+    if (rc < 0) return rc;
+    P.fast_tried = rc == 1;
+    if (P.fast_tried) {
+        if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        // the epilogue's last workgroup publishes this round's serial number in the block's header: the
+        // host polls that word instead of waiting for the runtime's completion signal (~5 us earlier)
+        P.serial = ++h->round_serial;
+        rc = csr ? launch_round_csr(h, cap, d_cnt, cap, d_idx, d_sc, coef_ld, h->pinned_dev, P.serial)
+                 : launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, P.serial);
+        if (rc) return rc;
+    }
+    P.active = true;
+    return SDPCUT_OK;
+}
+
+static int round_end(sdpcut_ctx *h, const void **block, int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat,
+                     int64_t *counters)
+{
+    if (!block || !cap_out || !n_out) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    if (!h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "no round pending on this handle");
+    const PendingRound P = h->pend;
+    h->pend.active = false;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int strat = P.strat;
+    const int64_t sel_size = P.sel_size, cap = P.cap;
+    const int32_t coef_ld = P.ld;
+    const bool csr = P.csr;
+    *n_out = 0;
+    *cap_out = cap;
+    *block = nullptr;
+    if (cap == 0) return sdpcut_rank(h, strat, sel_size, 0, nullptr, nullptr, n_total, new_strat, counters);
+    const size_t c = (size_t)cap;
     char *p = (char *)h->d_stage;
     p += 64;
     int64_t *d_idx = (int64_t *)p; p += c * 8;
@@ -761,37 +811,23 @@ static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_l
     double *d_rhs = (double *)p; p += c * 8;
     double *d_coef = (double *)p; p += c * 8 * (size_t)coef_ld;
     int32_t *d_ks = (int32_t *)p;
-    if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    int64_t *hdr = (int64_t *)h->pinned;
+    int rc;
     int64_t w = 0;
     bool have = false;
-    int64_t *hdr = (int64_t *)h->pinned;
-    if (csr) hdr[8] = hdr[9] = hdr[10] = 0;
-    // fast path: selection and rows are enqueued back to back; the epilogue kernel stores the
-    // results directly into the pinned host block (no copy engine); one synchronisation
-    const int64_t *d_cnt = nullptr;
-    rc = rank_fast_enqueue(h, strat, sel_size, cap, d_idx, d_sc, &d_cnt, stage, auto_regime);
-    if (rc < 0) return rc;
-    const bool fast_tried = rc == 1;
-    if (fast_tried) {
-        if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
-        // the epilogue's last workgroup publishes this round's serial number in the block's header: the
-        // host polls that word instead of waiting for the runtime's completion signal (~5 us earlier)
-        const int64_t serial = ++h->round_serial;
-        rc = csr ? launch_round_csr(h, cap, d_cnt, cap, d_idx, d_sc, coef_ld, h->pinned_dev, serial)
-                 : launch_round_rows(h, cap, d_cnt, d_idx, d_sc, coef_ld, h->pinned_dev, 64, serial);
-        if (rc) return rc;
-        rc = wait_round_done(h, hdr + 7, serial);
+    if (P.fast_tried) {
+        rc = wait_round_done(h, hdr + 7, P.serial);
         if (rc) return rc;
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
         if (have && csr && hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out");
     }
     ++h->stat_rounds;
-    if (fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
+    if (P.fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
     if (!have) {
         // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
         // (the fast attempt above already counted the strong candidates: no second attempt)
         const int64_t *c5 = (const int64_t *)h->pinned;
-        const int64_t hint = (fast_tried && strat == SDPCUT_STRAT_COMB && !c5[4]) ? c5[0] : -1;
+        const int64_t hint = (P.fast_tried && strat == SDPCUT_STRAT_COMB && !c5[4]) ? c5[0] : -1;
         rc = rank_on_device(h, strat, sel_size, cap, d_idx, d_sc, &w, n_total, new_strat, counters, hint);
         if (rc) return rc;
         if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
@@ -815,29 +851,19 @@ static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_l
     return SDPCUT_OK;
 }
 
-extern "C" {
-
-int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, const void **block,
-                             int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
+static int round_impl(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_ld, bool csr, const void **block,
+                      int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
 {
-    if (!h) return SDPCUT_EINVAL;
-    return round_impl(h, strat, sel_size, coef_ld, false, block, cap_out, n_out, n_total, new_strat, counters);
+    if (!block || !cap_out || !n_out) return sdpcut_fail(h, SDPCUT_EINVAL, "bad select_round arguments");
+    int rc = round_begin(h, strat, sel_size, coef_ld, csr);
+    if (rc) return rc;
+    return round_end(h, block, cap_out, n_out, n_total, new_strat, counters);
 }
 
-int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, sdpcut_round_csr_t *out)
+static int fill_csr_out(sdpcut_ctx *h, const void *block, sdpcut_round_csr_t *out)
 {
-    if (!h) return SDPCUT_EINVAL;
-    if (!out) return sdpcut_fail(h, SDPCUT_EINVAL, "out is NULL");
-    std::memset(out, 0, sizeof(*out));
-    int rc;
-    if (vars_values && (rc = sdpcut_set_point(h, vars_values))) return rc;
-    const void *block = nullptr;
-    const int32_t ld = h->row_len_max;
-    out->row_ld = ld;
-    rc = round_impl(h, strat, sel_size, ld, true, &block, &out->cap, &out->n_out, &out->n_total, &out->new_strat, out->counters);
-    if (rc) return rc;
     if (!block || out->cap == 0) return SDPCUT_OK;
-    const CsrLayout y = csr_layout(out->cap, ld);
+    const CsrLayout y = csr_layout(out->cap, out->row_ld);
     const char *b = (const char *)block;
     const int64_t *hdr = (const int64_t *)b;
     out->idx = (const int64_t *)(b + y.idx);
@@ -853,6 +879,45 @@ int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int6
     out->values = (const double *)(b + y.values);
     out->rhs = (const double *)(b + y.rhs);
     return SDPCUT_OK;
+}
+
+extern "C" {
+
+int sdpcut_select_round_view(sdpcut_handle h, int strat, int64_t sel_size, int32_t coef_ld, const void **block,
+                             int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat, int64_t *counters)
+{
+    if (!h) return SDPCUT_EINVAL;
+    return round_impl(h, strat, sel_size, coef_ld, false, block, cap_out, n_out, n_total, new_strat, counters);
+}
+
+int sdpcut_round_csr_begin(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size)
+{
+    if (!h) return SDPCUT_EINVAL;
+    int rc;
+    if (vars_values && (rc = sdpcut_set_point(h, vars_values))) return rc;
+    return round_begin(h, strat, sel_size, h->row_len_max, true);
+}
+
+int sdpcut_round_csr_end(sdpcut_handle h, sdpcut_round_csr_t *out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!out) return sdpcut_fail(h, SDPCUT_EINVAL, "out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    if (!h->pend.active || !h->pend.csr) return sdpcut_fail(h, SDPCUT_ESTATE, "no sdpcut_round_csr_begin pending on this handle");
+    const void *block = nullptr;
+    out->row_ld = h->pend.ld;
+    int rc = round_end(h, &block, &out->cap, &out->n_out, &out->n_total, &out->new_strat, out->counters);
+    if (rc) return rc;
+    return fill_csr_out(h, block, out);
+}
+
+int sdpcut_round_csr(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, sdpcut_round_csr_t *out)
+{
+    if (!h) return SDPCUT_EINVAL;
+    if (!out) return sdpcut_fail(h, SDPCUT_EINVAL, "out is NULL");
+    int rc = sdpcut_round_csr_begin(h, vars_values, strat, sel_size);
+    if (rc) { std::memset(out, 0, sizeof(*out)); return rc; }
+    return sdpcut_round_csr_end(h, out);
 }
 
 int sdpcut_round_view(sdpcut_handle h, const double *vars_values, int strat, int64_t sel_size, int32_t coef_ld,

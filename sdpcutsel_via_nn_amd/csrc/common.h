@@ -52,6 +52,14 @@ struct NetHost {
     double *d_blob = nullptr;   // one allocation behind all device pointers of dev
 };
 
+// a fused round between its two halves (capi.hip: round_begin / round_end)
+struct PendingRound {
+    bool active = false, csr = false, fast_tried = false;
+    int strat = 0;
+    int32_t ld = 0;
+    int64_t sel_size = 0, cap = 0, serial = 0;
+};
+
 struct sdpcut_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -123,6 +131,7 @@ struct sdpcut_ctx {
     bool point_inflight = false;   // a transfer out of point_stage may still be running
     int64_t round_serial = 0;      // completion word of the fused round (round_rows_kernel -> pinned header)
     uint32_t *d_done_ticket = nullptr;
+    PendingRound pend;
     // sdpcut_shard_finish_enqueue -> sdpcut_shard_finish_wait
     int64_t shard_pending_serial = 0, shard_pending_sel = 0;
     int32_t shard_pending_world = 0, shard_pending_ld = 0;

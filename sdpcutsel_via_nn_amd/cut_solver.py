@@ -119,6 +119,7 @@ class RankList(Sequence):
             return
         if self._b.point_token != self._point:
             raise RuntimeError("rank list is stale: the device now holds the scores of a newer LP point")
+        self._b.drain()
         idx, sc, total, _, _ = self._b.scorer.rank(self._strat, self._sel_size, max_out=self._n)
         self._idx, self._score, self._have = idx, sc, idx.shape[0]
 
@@ -322,6 +323,27 @@ class _Binding(object):
         self.scored = 0
         self.serial = 0
         self.set_arr = None      # [N, 5] index sets as arrays (vectorised entry building)
+        # a fused round begun on the scorer and not yet ended (sdpcut_round_csr_begin): (strat, head, LP point)
+        self.pending = None
+        # (binding, head) ranked by feasibility right after this one at the same LP point last time (the QCQP round's
+        # second cover, cut_select_qcqp.py:75-76): its round is begun together with this one's
+        self.follower = None
+        self.leader = None       # the binding this one follows (a follower never leads: no cycles)
+        self.wasted = 0          # speculative rounds nobody asked for
+
+    def begin(self, strat, head, vv, flags):
+        self.scorer.round_csr_begin(strat, head, point=vv)
+        self.note_point(vv, flags)
+        self.pending = (strat, head, self.point_copy)
+
+    def drain(self):
+        """end a round nobody collected (the scorer's block and scores are about to be used for something else)"""
+        if self.pending is not None:
+            self.pending = None
+            self.scorer.round_csr_end()
+            self.wasted += 1
+            if self.leader is not None:                   # the pair is not a pattern after all
+                self.leader.follower, self.leader = None, None
 
     def note_point(self, vv, scored=0):
         """the device now holds LP point ``vv`` (and the measures ``scored`` at it)"""
@@ -346,6 +368,7 @@ class _Binding(object):
         list was bound from, or fetched from the device for lists that only exist there."""
         if self.set_arr is not None:
             return self.set_arr[local_ids], self.ks[local_ids]
+        self.drain()
         return self.scorer.get_candidates(local_ids)
 
 
@@ -422,6 +445,7 @@ class GpuCutSelectionMixin(object):
 
     _gpu_device = 0
     _sparse_pair = None
+    _gpu_overlap = True      # begin the follower list's round together with the leader's (QCQP: two covers per LP point)
 
     # ------------------------------------------------------------------ a11 loader
     def _load_neural_nets(self):
@@ -498,6 +522,7 @@ class GpuCutSelectionMixin(object):
         uploaded through this binding (an in-place edit of the caller's array is a new point); the upload
         itself is an asynchronous copy out of pinned staging, so a redundant one costs little.
         :meth:`invalidate_point` forces the next call to upload."""
+        b.drain()
         vv = vars_values if (isinstance(vars_values, np.ndarray) and vars_values.dtype == np.float64 and
                              vars_values.flags.c_contiguous) else np.ascontiguousarray(vars_values, dtype=np.float64)
         same = b.point_copy is not None and b.point_copy.shape == vv.shape and np.array_equal(vv, b.point_copy)
@@ -514,6 +539,7 @@ class GpuCutSelectionMixin(object):
         """Forget which LP point the device holds: the next selection / generation uploads its point whatever it is
         (for callers that change device state behind the mixin's back, e.g. through the Scorer directly)."""
         for b in getattr(self, "_gpu_bindings", {}).values():
+            b.drain()
             b.point_copy, b.scored = None, 0
 
     # ------------------------------------------------------------------ a7-a9 selection
@@ -546,14 +572,31 @@ class GpuCutSelectionMixin(object):
         vv = vars_values if (isinstance(vars_values, np.ndarray) and vars_values.dtype == np.float64 and
                              vars_values.flags.c_contiguous) else np.ascontiguousarray(vars_values, dtype=np.float64)
         fused = None
+        # which list is ranked by feasibility right after which at the same point: the QCQP loop's pair (cut_select_qcqp.py:64-76)
+        last = getattr(self, "_gpu_last", None)
+        if (self._gpu_overlap and strat == 1 and last is not None and last[0] is not b and last[0].follower is None
+                and last[0].leader is None and b.follower is None and b.leader is None and 1 <= head <= _FUSED_HEAD_MAX and last[1].shape == vv.shape and np.array_equal(last[1], vv)):
+            last[0].follower, b.leader = (b, head), last[0]
         if 1 <= head <= _FUSED_HEAD_MAX and not (strat == 4 and sel_size == 0):
             # ONE library call for the whole separation step (cut_select_qp.py:165-182): LP point up, scores, ranking
-            # AND the assembled cuts of the head, which _gen_eigcuts_selected then only hands to the LP
-            fused = b.scorer.round_csr(strat, head, point=vv)
-            b.note_point(vv, flags)
+            # AND the assembled cuts of the head, which _gen_eigcuts_selected then only hands to the LP.  In two halves:
+            # between them the follower list's round is begun too, so both covers' device work overlaps.
+            pend = b.pending
+            if pend is not None and not (pend[0] == strat and pend[1] == head and pend[2].shape == vv.shape and np.array_equal(pend[2], vv)):
+                b.drain()
+                pend = None
+            if pend is None:
+                b.begin(strat, head, vv, flags)
+            f = b.follower
+            if f is not None and f[0].pending is None and f[0] is not b:
+                f[0].begin(1, f[1], vv, _capi.EIG)
+            b.pending = None
+            fused = b.scorer.round_csr_end()
             idx, score = fused["idx"].copy(), fused["score"].copy()
             total, new_strat, counters = fused["n_total"], fused["new_strat"], fused["counters"]
+            self._gpu_last = (b, b.point_copy)
         else:
+            self._gpu_last = None
             vv = self._gpu_point(b, vv, flags, cut_round)
             idx, score, total, new_strat, counters = b.scorer.rank(strat, sel_size, head)
         b.rank_serial += 1

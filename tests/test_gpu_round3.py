@@ -410,3 +410,93 @@ def test_qcqp_covers_split_on_the_device(pkg, name, dim):
     finally:
         a.close()
         b.close()
+
+
+# ----------------------------------------------------------------------------- round in two halves, overlapping lists
+def test_round_csr_in_two_halves_on_two_handles(pkg):
+    """sdpcut_round_csr_begin / _end: two handles begin before either ends; each ends with exactly what its one-call
+    round returns (general-path regimes included); a second begin, or another call, on a pending handle is refused."""
+    Q_arr, vv, S, ks = _mixed_workload(50, (2, 3, 4), 150000, seed=5)
+    Q2, vv2, S2, ks2 = _mixed_workload(50, (3,), 9000, seed=6)
+    x = vv[1275:]
+    iu = np.triu_indices(50)
+    psd = np.concatenate([np.minimum(x[iu[0]], x[iu[1]]), x])
+    a, b = pkg.Scorer(0), pkg.Scorer(0)
+    try:
+        for sc, (Q, cand, kk) in ((a, (Q_arr, S, ks)), (b, (Q_arr, S2, ks2))):
+            sc.set_builtin_networks(5)
+            sc.set_instance(50, Q)
+            sc.set_candidates(cand, kk)
+        fields = ("idx", "score", "lam", "row_entry", "indptr", "indices", "values", "rhs")
+        for point, sa, sb, sel_a, sel_b in ((vv, 4, 1, 5000, 5000), (vv, 1, 1, 16384, 100), (vv, 2, 4, 700, 9000),
+                                            (0.999 * psd + 0.001 * vv, 4, 1, 3000, 5000), (psd, 1, 4, 5000, 64)):
+            one_a = a.round_csr(sa, sel_a, point=point, copy=True)
+            one_b = b.round_csr(sb, sel_b, point=point, copy=True)
+            a.round_csr_begin(sa, sel_a, point=point)
+            b.round_csr_begin(sb, sel_b, point=point)
+            with pytest.raises(pkg.SdpCutError):
+                a.round_csr_begin(sa, sel_a, point=point)
+            with pytest.raises(pkg.SdpCutError):
+                b.score(1)
+            two_a = a.round_csr_end(copy=True)
+            two_b = b.round_csr_end(copy=True)
+            for one, two in ((one_a, two_a), (one_b, two_b)):
+                for f in fields:
+                    assert np.array_equal(one[f], two[f]), f
+                assert (one["n_total"], one["new_strat"], one["counters"]) == (two["n_total"], two["new_strat"], two["counters"])
+        with pytest.raises(pkg.SdpCutError):
+            a.round_csr_end()                  # nothing pending
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("strat", [1, 2, 4])
+def test_qcqp_loop_begins_both_covers_rounds_together(pkg, oracle, golden_qcqp, strat):
+    """The reference's QCQP loop ranks the objective cover, then the constraints cover by feasibility at the same point
+    (cut_select_qcqp.py:64-78).  The mixin learns that pair in the first round and from then on begins the second
+    list's round together with the first's; the rounds' results are those of a solver that does not overlap, no
+    speculative round is wasted, and a break of the pattern (another point for the second list) is noticed."""
+    from conftest import agg_from_arrays
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolverQCQP
+    g = golden_qcqp
+    n = int(g["nb_vars"])
+    L = n * (n + 1) // 2
+    agg_o = agg_from_arrays(oracle, g["obj_set_inds"], g["obj_k"], n, g["Q_arr"])
+    agg_c = agg_from_arrays(oracle, g["cons_set_inds"], g["cons_k"], n, g["Q_arr"])
+    rng = np.random.default_rng(11)
+    points = [g["vars"]] + [harness.random_mccormick_point(n, rng) for _ in range(4)]
+
+    def solver(overlap):
+        cs = CutSolverQCQP()
+        cs._gpu_overlap = overlap
+        cs.set_instance(n, g["Q_arr"], agg_o, dim=3, my_prob=harness.LinearRelaxation(np.zeros(L + n)))
+        return cs
+    x, y = solver(True), solver(False)
+    for r, vv in enumerate(points):
+        out = []
+        for cs in (x, y):
+            cs._my_prob = harness.LinearRelaxation(np.zeros(L + n))
+            res = cs.select_and_generate_round(strat, vv, r + 1, 40, agg_o, agg_c)
+            st = cs._my_prob.linear_constraints
+            out.append((res[0], res[2], res[3], [tuple(e[0]) if not isinstance(e[0], int) else e[0] for e in res[1]],
+                        [e[1] for e in res[1]], st.csr_parts(), st.rhs))
+        (s1, n1, o1, ids1, sc1, csr1, rhs1), (s2, n2, o2, ids2, sc2, csr2, rhs2) = out
+        assert (s1, n1, o1) == (s2, n2, o2) and ids1 == ids2 and sc1 == sc2 and rhs1 == rhs2
+        assert all(np.array_equal(p, q) for p, q in zip(csr1, csr2))
+    bo, bc = x._gpu_bindings[id(agg_o)], x._gpu_bindings[id(agg_c)]
+    assert bo.follower is not None and bo.follower[0] is bc and bo.wasted == bc.wasted == 0 and bc.pending is None
+    assert all(b.follower is None for b in y._gpu_bindings.values())
+    # the pattern breaks: the objective cover is ranked (the constraints cover's round begins with it), then the
+    # constraints cover is asked about ANOTHER point -- the speculative round is dropped, the answer is the right one
+    x._agg_list = agg_o
+    x._sel_eigcut_by_ordering_on_measure(2, points[1], 9)
+    assert bc.pending is not None
+    x._agg_list = agg_c
+    got = x._sel_eigcut_by_ordering_on_measure(1, points[2], 9)
+    y._agg_list = agg_c
+    want = y._sel_eigcut_by_ordering_on_measure(1, points[2], 9)
+    assert bc.wasted == 1 and bc.pending is None
+    assert np.array_equal(got.ids(40), want.ids(40)) and np.array_equal(got.scores(40), want.scores(40))
+    x._agg_list = y._agg_list = agg_o
