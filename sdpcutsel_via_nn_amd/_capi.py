@@ -277,6 +277,7 @@ class Scorer(object):
 
     def get_candidates(self, local_idx):
         """-> (set_inds int32 [count, 5] padded with -1, ks int32 [count]) of candidates by local index"""
+        self.drop_pending()      # (lists that live on the device are read through their scorer whenever somebody indexes them)
         idx = np.ascontiguousarray(local_idx, dtype=np.int64)
         out = np.empty((max(idx.shape[0], 1), 5), dtype=np.int32)
         ks = np.empty(max(idx.shape[0], 1), dtype=np.int32)
@@ -434,12 +435,24 @@ class Scorer(object):
         vv = self._csr_point(point)
         self.round_count += 1
         self._check(self._lib.sdpcut_round_csr_begin(self._h, _ptr(vv, _dp), int(strat), int(sel_size)))
+        self.pending = object()          # identifies THIS begun round until it is ended (or dropped)
+        return self.pending
 
     def round_csr_end(self, copy=False):
         """Second half of round_csr (sdpcut_round_csr_end): wait for the round begun on this Scorer; the same dict."""
         out = self._csr_out()
+        self.pending = None
         self._check(self._lib.sdpcut_round_csr_end(self._h, ctypes.byref(out)))
         return self._csr_unpack(out, copy)
+
+    pending = None
+
+    def drop_pending(self):
+        """end a begun round nobody will collect (its results are discarded); True if there was one"""
+        if self.pending is None:
+            return False
+        self.round_csr_end()
+        return True
 
     def _csr_point(self, point):
         if point is None:

@@ -278,6 +278,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
                        int64_t n_params)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
     if (n_layers < 2 || n_layers > MAX_LAYERS || !widths || !params)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad layer description");
@@ -427,6 +428,7 @@ int sdpcut_set_network(sdpcut_handle h, int k, int n_layers, const int32_t *widt
 int sdpcut_set_instance(sdpcut_handle h, int32_t nb_vars, const double *Q_arr)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (nb_vars < 2 || nb_vars > 40000 || !Q_arr) return sdpcut_fail(h, SDPCUT_EINVAL, "bad instance");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, sdpcut_sync(h));
@@ -445,6 +447,7 @@ int sdpcut_set_candidates(sdpcut_handle h, int64_t N, const int32_t *set_inds, i
                           int64_t global_base)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (N < 0 || N > 0x7fffffffLL || (N > 0 && (!set_inds || !ks)) || ld < 2)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad candidate list");
@@ -519,7 +522,7 @@ int sdpcut_point_buffer(sdpcut_handle h, double **buf)
 int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
+    SDPCUT_NO_PENDING(h);
     if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "vars_values is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -552,7 +555,7 @@ int sdpcut_set_point(sdpcut_handle h, const double *vars_values)
 int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
+    SDPCUT_NO_PENDING(h);
     if (!h->d_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!d_vars_values) return sdpcut_fail(h, SDPCUT_EINVAL, "d_vars_values is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -567,7 +570,7 @@ int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values)
 int sdpcut_score(sdpcut_handle h, uint32_t flags)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
+    SDPCUT_NO_PENDING(h);
     if (!(flags & (SDPCUT_EIG | SDPCUT_NN)) || (flags & ~(uint32_t)(SDPCUT_EIG | SDPCUT_NN)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "flags must be a combination of SDPCUT_EIG and SDPCUT_NN");
     if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
@@ -582,6 +585,7 @@ int sdpcut_score(sdpcut_handle h, uint32_t flags)
 int sdpcut_get_scores(sdpcut_handle h, double *eigmin, double *obj_improve)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (eigmin) {
         if (!(h->scored & SDPCUT_EIG)) return sdpcut_fail(h, SDPCUT_ESTATE, "eigenvalues not scored");
@@ -611,6 +615,7 @@ int sdpcut_rank_device(sdpcut_handle h, int strat, int64_t sel_size, int64_t max
                        int64_t *counters)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     int rc = check_rank_args(h, strat);
     if (rc) return rc;
     if (max_out < 0 || (max_out > 0 && (!d_idx_out || !d_score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
@@ -627,7 +632,7 @@ int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, i
                 int64_t *n_total, int32_t *new_strat, int64_t *counters)
 {
     if (!h) return SDPCUT_EINVAL;
-    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending: end it first");
+    SDPCUT_NO_PENDING(h);
     if (max_out < 0 || (max_out > 0 && (!idx_out || !score_out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad output");
     HIP_TRY(h, hipSetDevice(h->device));
     int64_t cap = max_out < h->N ? max_out : h->N;
@@ -649,6 +654,7 @@ int sdpcut_rank(sdpcut_handle h, int strat, int64_t sel_size, int64_t max_out, i
 int sdpcut_rank_fetch(sdpcut_handle h, int64_t offset, int64_t count, int64_t *idx_out, double *score_out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (h->last_total < 0) return sdpcut_fail(h, SDPCUT_ESTATE, "no ranking available: call sdpcut_rank first");
     if (offset < 0 || count < 0 || offset + count > h->last_total || (count > 0 && (!idx_out || !score_out)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "window outside the last ranking");
@@ -670,6 +676,7 @@ int sdpcut_merge_topk_device(sdpcut_handle h, int64_t count, const void *d_score
                              const void *d_ids, int64_t max_out, void *d_score_out, void *d_id_out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (count < 0 || max_out < 0 || (count > 0 && max_out > 0 && (!d_scores || !d_ids || !d_score_out || !d_id_out)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad merge arguments");
     if (count > 0x7fffffffLL) return sdpcut_fail(h, SDPCUT_EINVAL, "merge too large");
@@ -681,6 +688,7 @@ int sdpcut_merge_topk_device(sdpcut_handle h, int64_t count, const void *d_score
 int sdpcut_gather_scores_device(sdpcut_handle h, int64_t count, const void *d_ids, void *d_eig_out, void *d_obj_out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (count < 0 || (count > 0 && !d_ids)) return sdpcut_fail(h, SDPCUT_EINVAL, "bad gather arguments");
     if ((d_eig_out && !(h->scored & SDPCUT_EIG)) || (d_obj_out && !(h->scored & SDPCUT_NN)))
         return sdpcut_fail(h, SDPCUT_ESTATE, "sdpcut_score with the needed flags first");
@@ -692,6 +700,7 @@ int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *
                     int64_t *cols, int32_t *ks)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (!h->have_point || !h->d_set_orig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
     if (count < 0 || (count > 0 && (!idx || !lam_min || !coef || !rhs || !cols || !ks)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad cut_rows arguments");
@@ -957,6 +966,7 @@ int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho,
                      double *eigvals, double *evecs)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
     if (count < 0 || (count > 0 && (!x_rho || !X_rho || !eigvals))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad eig_batch arguments");
     if (count == 0) return SDPCUT_OK;
@@ -979,6 +989,7 @@ int sdpcut_eig_batch(sdpcut_handle h, int k, int64_t count, const double *x_rho,
 int sdpcut_nn_batch(sdpcut_handle h, int k, int64_t count, const double *inputs, double *out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
     if (!h->net[k].set) return sdpcut_fail(h, SDPCUT_ESTATE, "no network set for this candidate size");
     if (count < 0 || (count > 0 && (!inputs || !out))) return sdpcut_fail(h, SDPCUT_EINVAL, "bad nn_batch arguments");
@@ -1020,6 +1031,7 @@ int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, do
                         int64_t *n_written)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (!h->have_point) return sdpcut_fail(h, SDPCUT_ESTATE, "set_point first");
     if (max_out < 0 || (max_out > 0 && (!entry_out || !viol_out)) || !n_violated || !n_written)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad tri_separate arguments");

@@ -60,6 +60,13 @@ struct PendingRound {
     int64_t sel_size = 0, cap = 0, serial = 0;
 };
 
+// every entry point that touches the handle's scores, staging or pinned block refuses to run between the two halves of a round
+#define SDPCUT_NO_PENDING(h)                                                                                              \
+    do {                                                                                                                  \
+        if ((h)->pend.active)                                                                                             \
+            return sdpcut_fail((h), SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending on this handle: end it first"); \
+    } while (0)
+
 struct sdpcut_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;

@@ -39,6 +39,7 @@ static const double *builtin_params(int i)
 extern "C" int sdpcut_set_builtin_networks(sdpcut_handle h, int max_k)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (max_k < 2 || max_k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "max_k must be 2..5");
     for (int i = 0; i < 4 && BUILTIN_K[i] <= max_k; ++i) {
         int rc = sdpcut_set_network(h, BUILTIN_K[i], BUILTIN_NLAYERS[i], BUILTIN_WIDTHS[i], builtin_params(i),

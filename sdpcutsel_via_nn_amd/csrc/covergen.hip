@@ -324,6 +324,7 @@ extern "C" int sdpcut_set_candidates_cover(sdpcut_handle h, const uint8_t *adjac
                                            int64_t *count_out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (!adjacency || dim < 3 || dim > SDPCUT_MAX_K || !count_out || max_subs < 0)
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad cover arguments (dim must be 3..5)");

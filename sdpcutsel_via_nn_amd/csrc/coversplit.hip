@@ -91,6 +91,8 @@ extern "C" int sdpcut_set_candidates_cover_split(sdpcut_handle h_in, sdpcut_hand
                                                  const uint8_t *adjacency_all, int32_t dim, int64_t *n_in, int64_t *n_out)
 {
     if (!h_in || !h_out) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h_in);
+    SDPCUT_NO_PENDING(h_out);
     sdpcut_ctx *h = h_out;
     if (h_in == h_out || h_in->device != h_out->device) return sdpcut_fail(h, SDPCUT_EINVAL, "cover_split: two handles on one device");
     if (h_in->nb_vars == 0 || h_in->nb_vars != h_out->nb_vars) return sdpcut_fail(h, SDPCUT_ESTATE, "cover_split: set_instance (same instance) on both handles first");

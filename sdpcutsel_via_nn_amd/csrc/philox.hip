@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void philox_sets_kernel(uint64_t seed, uint64_
 extern "C" int sdpcut_set_candidates_philox(sdpcut_handle h, int32_t k, int64_t N, uint64_t seed, int64_t first_id)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (h->nb_vars == 0) return sdpcut_fail(h, SDPCUT_ESTATE, "set_instance first");
     if (k < 2 || k > SDPCUT_MAX_K) return sdpcut_fail(h, SDPCUT_EINVAL, "k must be 2..5");
     if (N < 0 || N > 0x7fffffffLL || first_id < 0) return sdpcut_fail(h, SDPCUT_EINVAL, "bad candidate count / first id");
@@ -56,6 +57,7 @@ extern "C" int sdpcut_get_candidates(sdpcut_handle h, int64_t count, const int64
                                      int32_t *ks_out)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (count < 0 || (count > 0 && (!idx || !set_inds_out || !ks_out)))
         return sdpcut_fail(h, SDPCUT_EINVAL, "bad get_candidates arguments");
     if (!h->d_set_orig) return sdpcut_fail(h, SDPCUT_ESTATE, "no candidate list");

@@ -93,6 +93,7 @@ __global__ void shard_mergerank_kernel(int world, int64_t count, int fields, int
 extern "C" int sdpcut_shard_head_device(sdpcut_handle h, int strat, int64_t count, void *d_record)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     if (count < 1 || count > 16384 || !d_record) return sdpcut_fail(h, SDPCUT_EINVAL, "shard head: count must be 1..16384");
     const bool comball = strat == SDPCUT_PART_COMBALL;
     if (strat != SDPCUT_STRAT_FEAS && strat != SDPCUT_STRAT_OPT && strat != SDPCUT_PART_STRONG && !comball)
@@ -151,6 +152,7 @@ extern "C" int sdpcut_shard_finish_enqueue(sdpcut_handle h, int32_t world, int64
                                            int64_t pitch_words, int64_t sel_size, int32_t coef_ld)
 {
     if (!h) return SDPCUT_EINVAL;
+    SDPCUT_NO_PENDING(h);
     const int64_t rl = SHARD_HDR + (int64_t)fields * count;
     if (pitch_words == 0) pitch_words = rl;
     if (world < 1 || count < 1 || !d_allrec || sel_size < 1 || sel_size > (int64_t)world * count || (fields != 2 && fields != 3) ||

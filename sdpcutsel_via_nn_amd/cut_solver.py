@@ -324,7 +324,7 @@ class _Binding(object):
         self.serial = 0
         self.set_arr = None      # [N, 5] index sets as arrays (vectorised entry building)
         # a fused round begun on the scorer and not yet ended (sdpcut_round_csr_begin): (strat, head, LP point)
-        self.pending = None
+        self._pending = None
         # (binding, head) ranked by feasibility right after this one at the same LP point last time (the QCQP round's
         # second cover, cut_select_qcqp.py:75-76): its round is begun together with this one's
         self.follower = None
@@ -332,15 +332,26 @@ class _Binding(object):
         self.wasted = 0          # speculative rounds nobody asked for
 
     def begin(self, strat, head, vv, flags):
-        self.scorer.round_csr_begin(strat, head, point=vv)
+        token = self.scorer.round_csr_begin(strat, head, point=vv)
         self.note_point(vv, flags)
-        self.pending = (strat, head, self.point_copy)
+        self._pending = (token, strat, head, self.point_copy)
+
+    @property
+    def pending(self):
+        """(strat, head, LP point) of the round begun through this binding and still pending on its scorer, or None"""
+        p = self._pending
+        if p is not None and self.scorer.pending is not p[0]:       # somebody ended or dropped it on the scorer
+            p = self._pending = None
+        return None if p is None else p[1:]
+
+    def end(self):
+        self._pending = None
+        return self.scorer.round_csr_end()
 
     def drain(self):
         """end a round nobody collected (the scorer's block and scores are about to be used for something else)"""
         if self.pending is not None:
-            self.pending = None
-            self.scorer.round_csr_end()
+            self.end()
             self.wasted += 1
             if self.leader is not None:                   # the pair is not a pattern after all
                 self.leader.follower, self.leader = None, None
@@ -590,8 +601,7 @@ class GpuCutSelectionMixin(object):
             f = b.follower
             if f is not None and f[0].pending is None and f[0] is not b:
                 f[0].begin(1, f[1], vv, _capi.EIG)
-            b.pending = None
-            fused = b.scorer.round_csr_end()
+            fused = b.end()
             idx, score = fused["idx"].copy(), fused["score"].copy()
             total, new_strat, counters = fused["n_total"], fused["new_strat"], fused["counters"]
             self._gpu_last = (b, b.point_copy)

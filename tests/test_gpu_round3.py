@@ -446,6 +446,18 @@ def test_round_csr_in_two_halves_on_two_handles(pkg):
                 assert (one["n_total"], one["new_strat"], one["counters"]) == (two["n_total"], two["new_strat"], two["counters"])
         with pytest.raises(pkg.SdpCutError):
             a.round_csr_end()                  # nothing pending
+        # reading the list of a scorer with a begun round drops that round first (lists that live on the device are read
+        # through their scorer); the library itself refuses every stateful call on a pending handle
+        tok = b.round_csr_begin(1, 100, point=vv)
+        assert b.pending is tok
+        for call in (lambda: b.set_point(vv), lambda: b.rank(1, 10, max_out=10), lambda: b.cut_rows(np.arange(3)),
+                     lambda: b.set_candidates(S2, ks2), lambda: b.get_scores()):
+            with pytest.raises(pkg.SdpCutError):
+                call()
+        got, kk = b.get_candidates(np.arange(7))
+        assert b.pending is None and np.array_equal(got[:, :3], S2[:7, :3]) and not b.drop_pending()
+        again = b.round_csr(1, 100, point=vv, copy=True)
+        assert again["idx"].shape[0] == 100
     finally:
         a.close()
         b.close()
