@@ -287,8 +287,10 @@ def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     gbs = bytes_per * n_local / (k_ms * 1e-3) / 1e9
     return {"value": n_local / dt, "unit": "candidates/s", "ms_per_step": dt * 1e3, "steps": steps, "strategy": 1,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "eig_only_kernel<%d, true>" % K,      # <largest size class present, counts the selection's leading digit> "kernel_ms": k_ms,
-                         "candidates_per_launch": n_local, "bytes_per_candidate": bytes_per,
+                         "traffic": None,
+                         "kernel": "eig_only_kernel<%d, true>" % K,      # <largest size class present, counts the selection's leading digit>
+                         "kernel_ms": k_ms, "candidates_per_launch": n_local, "bytes_per_candidate": bytes_per,
+                         "issue": issue_floor(K, n_local, k_ms, "eig"),
                          "note": "gather + register Jacobi, no MLP: bound by VALU instruction issue (DESIGN.md section 5), "
                                  "the HBM figure is the algorithmic one"}}
 
@@ -308,13 +310,31 @@ class _StdoutToStderr(object):
         os.close(self._saved)
 
 
+# Instruction-issue floor of the two hot kernels at k = 3, from the PMC passes kept under profiles/ (instructions per launch of
+# 10^6 candidates; a VALU instruction occupies its SIMD for 4 cycles, a quarter-rate transcendental for 16, an fp64 MFMA for 64):
+# what the kernel would take if its SIMDs never waited.  Not a roofline in the HBM / MFMA sense -- the bound these kernels run into.
+ISSUE_CYCLES_PER_CAND = {
+    ("eig", 3): ((18.64 - 1.26) * 4 + 1.26 * 16, "profiles/r03_eig_k3_kernel_pmc.txt"),
+    ("mfma", 3): ((5111 * 4 + 348 * 64) / 64.0, "profiles/r02b_k3_score_kernel_pmc.txt (5111 VALU + 348 MFMA per 64-candidate strip)"),
+}
+SIMDS, CLOCK_GHZ = 1024, 2.4
+
+
+def issue_floor(k, n_per_launch, kernel_ms, which):
+    e = ISSUE_CYCLES_PER_CAND.get((which, k))
+    if e is None:
+        return None
+    floor_ms = e[0] * n_per_launch / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+    return {"floor_ms": floor_ms, "frac": floor_ms / kernel_ms, "clock_GHz": CLOCK_GHZ, "source": e[1]}
+
+
 def roofline(k, n_per_launch, kernel_ms, traffic, counts_digit=True, variant="mfma"):
     tflops = FLOPS_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e12
     gbs = BYTES_PER_CAND[k] * n_per_launch / (kernel_ms * 1e-3) / 1e9
     return {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
             "traffic": traffic, "kernel": kernel_name(k, counts_digit and variant == "mfma", variant), "kernel_ms": kernel_ms, "candidates_per_launch": n_per_launch,
             "flops_per_candidate": FLOPS_PER_CAND[k], "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-            "bytes_per_candidate": BYTES_PER_CAND[k]}
+            "bytes_per_candidate": BYTES_PER_CAND[k], "issue": issue_floor(k, n_per_launch, kernel_ms, variant)}
 
 
 def main():
