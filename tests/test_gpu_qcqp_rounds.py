@@ -62,13 +62,20 @@ def test_replay_of_the_reference_qcqp_rounds(path):
             # (round 1 ranks at the McCormick vertex, where whole groups of sub-matrices are exactly singular alike and
             # LAPACK's last bits order them); an id chosen by one side only sits in the run that
             # reaches the end of the head.
+            # Entries of the objective cover may change places only under the combined strategy's every-entry-visited
+            # regime, where they, too, carry -eigval (cut_select_qp.py:619-621), and only inside a run of scores equal to
+            # 1e-12 relative (q_50_25_75_1, round 6: two sub-matrices with the same smallest eigenvalue, 4 ulps apart in
+            # the reference's list, 1 ulp apart -- the other way round -- here).
             is_obj = g[p + "is_obj"]
             for b in np.flatnonzero(~same):
-                assert not is_obj[b], (r, int(b))
+                tie = tol[b]
+                if is_obj[b]:
+                    assert strat == 4 and 0.0 < ref[b] < 1.0, (r, int(b))       # a feasibility score, not obj_improve + 1000
+                    tie = 1e-12 * abs(ref[b])
                 lo = hi = b
-                while lo > 0 and abs(ref[lo - 1] - ref[b]) <= tol[b] and not is_obj[lo - 1]:
+                while lo > 0 and abs(ref[lo - 1] - ref[b]) <= tie and is_obj[lo - 1] == is_obj[b]:
                     lo -= 1
-                while hi + 1 < len(ref) and abs(ref[hi + 1] - ref[b]) <= tol[b]:
+                while hi + 1 < len(ref) and abs(ref[hi + 1] - ref[b]) <= tie:
                     hi += 1
                 if b == len(ref) - 1:
                     continue          # the run continues behind the head: the two scores agree (asserted above), the ids need not
@@ -107,5 +114,8 @@ def test_live_qcqp_loop_follows_the_reference_trajectory(path):
     ref_cuts = [int(g["r%02d_nb_cuts" % r]) for r in range(1, rounds + 1)]
     assert len(cuts) == rounds + 1 and abs(sum(cuts) - sum(ref_cuts)) <= max(2, 0.1 * sum(ref_cuts)), (cuts, ref_cuts)
     if strat0 != 5:
-        # rounds 1-3 run before any of that can matter: identical to the recorded ones
-        assert np.all(np.abs(bounds[:3] - ref[:3]) <= 1e-6 * np.maximum(1.0, np.abs(ref[:3]))) or strat0 == 1
+        # rounds 1-3 run before any of that can matter: the recorded bounds -- to 1e-5: at the first vertex (x = 0.5 throughout on
+        # the dense q_20_20_100_2) 3 of the 57 selected sub-matrices have a DOUBLE smallest eigenvalue, whose eigenvector -- hence
+        # the cut -- is any unit vector of a plane; LAPACK's and the device's differ, both cuts are valid, the bound after them
+        # differs by 1.5e-6 relative
+        assert np.all(np.abs(bounds[:3] - ref[:3]) <= 1e-5 * np.maximum(1.0, np.abs(ref[:3]))) or strat0 == 1
