@@ -258,6 +258,23 @@ def bench_c5(device_index, steps, warm=10):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         out["strategy_%d" % strat] = {"round_ms": ms, "cuts": r[2], "candidates_per_s": (n_o + n_c) / (ms * 1e-3)}
+    # the same rounds with the two lists' rounds strictly one after the other (the pairing of DESIGN.md section 5 switched off)
+    cs._gpu_overlap = False
+    for b in cs._gpu_bindings.values():
+        b.drain()
+        b.follower = b.leader = None
+    for strat in (4, 1):
+        def one():
+            cs._my_prob.linear_constraints = harness._RowStore()
+            return cs.select_and_generate_round(strat, vv, 1, SEL, cover_obj, cover_cons)
+        for _ in range(warm):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        out["strategy_%d" % strat]["round_ms_lists_one_after_the_other"] = (time.perf_counter() - t0) / steps * 1e3
     sc_o.close()
     sc_c.close()
     return out

@@ -30,6 +30,12 @@ def main():
             X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
         points.append(np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)]))
     sizes = [count, max(count // 7, 1), 8192, 5000, 300]
+    # (r3) a second handle whose rounds are begun together with the first one's (sdpcut_round_csr_begin / _end): two streams at once
+    sc2 = _capi.Scorer(0)
+    sc2.set_network(3, *networks.load_network(3))
+    sc2.set_instance(n, wl["Q_arr"])
+    sc2.set_candidates(wl["set_inds"][count // 3:count // 3 + min(count // 2, 300000)], wl["ks"][count // 3:count // 3 + min(count // 2, 300000)])
+    pairs = 0
     first, rounds, per_kind = {}, 0, {}
     t_end = time.time() + budget
     cur_size = None
@@ -43,7 +49,24 @@ def main():
             strat = int(rng.choice([1, 2, 4]))
             sel = int(rng.choice([1, 64, 777, 5000]))
             csr = bool(rng.integers(0, 2))      # (r3) either epilogue: padded rows or the CSR block assembled on the device
-            if csr:
+            if csr and rng.integers(0, 3) == 0:
+                p2, strat2, sel2 = int(rng.integers(0, len(points))), int(rng.choice([1, 2, 4])), int(rng.choice([64, 5000]))
+                sc.round_csr_begin(strat, sel, point=points[p])
+                sc2.round_csr_begin(strat2, sel2, point=points[p2])
+                r = sc.round_csr_end()
+                r2 = sc2.round_csr_end()
+                key2 = ("second handle", p2, strat2, sel2)
+                got2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r2.items()}
+                pairs += 1
+                if key2 not in first:
+                    first[key2] = got2
+                else:
+                    for k, v in got2.items():
+                        same = np.array_equal(v, first[key2][k], equal_nan=True) if isinstance(v, np.ndarray) else v == first[key2][k]
+                        if not same:
+                            print("MISMATCH round %d kind %s field %s" % (rounds, key2, k), flush=True)
+                            sys.exit(1)
+            elif csr:
                 r = sc.round_csr(strat, sel, point=points[p])
             else:
                 sc.set_point(points[p])
@@ -63,10 +86,12 @@ def main():
                     sys.exit(1)
         if rounds % 2000 < 40:
             print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
-    fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)
-    print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues), every repeat bit-identical; "
-          "%d rounds answered by the path without in-kernel waits" % (rounds, len(first), sizes, len(points), fallbacks))
+    fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc2.get_stat(_capi.STAT_SELECT_FALLBACKS)
+    print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues; %d of them begun together with a round "
+          "on a second handle and ended after it), every repeat bit-identical; %d rounds answered by the path without in-kernel waits"
+          % (rounds, len(first), sizes, len(points), pairs, fallbacks))
     sc.close()
+    sc2.close()
 
 
 if __name__ == "__main__":
