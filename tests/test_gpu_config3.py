@@ -78,24 +78,39 @@ def test_replay_of_the_reference_trajectory(path):
             assert np.all(np.abs(res["score"] - ref_score) <= tol), (r, np.abs(res["score"] - ref_score).max())
             same = res["idx"] == ref_ids
             n_set = int(np.setdiff1d(res["idx"], ref_ids).size)
-            # The reference's ORDER, position by position.  The three dim-4 trajectories (32 rounds, 160 000 positions) are
-            # reproduced without a single differing position and must stay so.  In the dim-3 trajectory of spar125-075-2
-            # two pairs of neighbours of round 2 change places: their reference scores are EQUAL to the last bit or to one
-            # ulp (obj_improve + 1000 swallows the low bits of obj_improve, cut_select_qp.py:611), i.e. the reference's own
-            # order there is the order of two obj_improve values 1e-14 apart -- below the 1e-11 the two MLP evaluations
-            # agree to.  Such a swap is admitted only between entries whose reference scores agree to 1e-12 relative, and
-            # never changes the selected set.
+            # The reference's ORDER, position by position (profiles/r03_trajectory_replay.txt).  Ten recorded trajectories, 199
+            # rounds: spar125-075-{1,2,3} dim 4 combined (20 rounds each, 1.6-1.7e6 candidates), spar125-050-1 / spar100-050-1 /
+            # spar070-050-1 dim 5 combined (mixed 2..5-variable covers), spar125-075-1 dim 3 and spar090-075-1 dim 4 optimality,
+            # spar125-075-2 dim 3 combined, spar080-075-1 dim 4 feasibility from the first round.  195 rounds are reproduced
+            # without a single differing position and must stay so.  Two kinds of exception, both inside EXACT ties of the
+            # reference's own scores (asserted run by run below) and nowhere else:
+            #  * the dim-3 trajectory of spar125-075-2, round 2: two pairs of neighbours change places; their reference scores
+            #    are EQUAL to the last bit or to one ulp (obj_improve + 1000 swallows the low bits of obj_improve,
+            #    cut_select_qp.py:611), i.e. the reference's own order there is the order of two obj_improve values 1e-14 apart
+            #    -- below the 1e-11 the two MLP evaluations agree to.  The selected set is identical.
+            #  * the pure-feasibility trajectory, rounds 1-3 (see below).
             if not same.all():
-                assert "_d3_" in os.path.basename(path), (r, strat, np.flatnonzero(~same)[:10].tolist())
-                bad = np.flatnonzero(~same)
-                assert bad.size <= 4 and n_set == 0, (r, bad.tolist(), n_set)
-                for b in bad:
-                    lo, hi = b, b
-                    while lo > 0 and abs(ref_score[lo - 1] - ref_score[b]) <= 1e-12 * abs(ref_score[b]):
-                        lo -= 1
-                    while hi + 1 < w and abs(ref_score[hi + 1] - ref_score[b]) <= 1e-12 * abs(ref_score[b]):
-                        hi += 1
-                    assert hi > lo and res["idx"][b] in ref_ids[lo:hi + 1], (r, int(b))
+                base = os.path.basename(path)
+                assert "_d3_" in base or base.endswith("_s1.npz"), (r, strat, np.flatnonzero(~same)[:10].tolist())
+                # runs of reference scores equal to 1e-12 relative; a differing position must lie in such a run, and the run
+                # holds the same ids on both sides unless it reaches the end of the head (the tie group straddles the cut)
+                brk = np.flatnonzero(np.abs(np.diff(ref_score)) > 1e-12 * np.abs(ref_score[:-1]))
+                starts, stops = np.concatenate([[0], brk + 1]), np.concatenate([brk + 1, [w]])
+                run_of = np.repeat(np.arange(starts.size), stops - starts)
+                for k in np.unique(run_of[~same]):
+                    lo, hi = int(starts[k]), int(stops[k])
+                    assert hi - lo > 1, (r, lo)
+                    if hi < w:
+                        assert np.array_equal(np.sort(res["idx"][lo:hi]), np.sort(ref_ids[lo:hi])), (r, lo, hi)
+                if "_d3_" in base:
+                    assert (~same).sum() <= 4 and n_set == 0, (r, np.flatnonzero(~same).tolist(), n_set)
+                else:
+                    # A trajectory that runs pure feasibility from the FIRST round starts at the McCormick vertex: round 1 of
+                    # spar080-075-1 has TWO distinct scores in its head of 5000, round 2 (the LP after 5000 cuts out of those
+                    # ties) 245, round 3 eight pairs of equal eigenvalues one ulp apart; from round 4 on every position is the
+                    # reference's.  The deviation DESIGN.md section 2 states for structured vertices, here measured along a
+                    # recorded trajectory: list lengths, scores (1.2e-15) and cut counts are the reference's in all 20 rounds.
+                    assert strat == 1 and r <= 3, (r, strat, int((~same).sum()))
             nb_cuts = int((res["lam"] < -1e-15).sum())
             assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
             report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "
