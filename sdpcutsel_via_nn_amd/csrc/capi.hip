@@ -242,6 +242,23 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
+    case SDPCUT_OPT_STREAM_PRIORITY: {
+        SDPCUT_NO_PENDING(h);
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, sdpcut_sync(h));
+        int least = 0, greatest = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        hipStream_t s = nullptr;
+        HIP_TRY(h, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, value != 0 ? greatest : least));
+        const bool on_own = h->stream == h->own_stream;
+        if (h->own_stream) {
+            HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+            (void)hipStreamDestroy(h->own_stream);
+        }
+        h->own_stream = s;
+        if (on_own) h->stream = s;
+        return SDPCUT_OK;
+    }
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown option");
 }

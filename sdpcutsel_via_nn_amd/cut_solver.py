@@ -196,7 +196,7 @@ class RankList(Sequence):
             rng = range(*key.indices(self._n))
             if not len(rng):
                 return []
-            self._need(max(rng) + 1)
+            self._need((rng[-1] if rng.step > 0 else rng[0]) + 1)      # (max(rng) walks the range: 16 us for a head of 5000)
             if rng.step == 1 and rng.start == 0:
                 return RankListHead(self, rng.stop)
             if rng.step == 1:
@@ -330,6 +330,7 @@ class _Binding(object):
         self.follower = None
         self.leader = None       # the binding this one follows (a follower never leads: no cycles)
         self.wasted = 0          # speculative rounds nobody asked for
+        self.prioritised = False # its scorer's stream has been given the device's highest priority (a short list beside a long one)
 
     def begin(self, strat, head, vv, flags):
         token = self.scorer.round_csr_begin(strat, head, point=vv)
@@ -596,10 +597,20 @@ class GpuCutSelectionMixin(object):
             if pend is not None and not (pend[0] == strat and pend[1] == head and pend[2].shape == vv.shape and np.array_equal(pend[2], vv)):
                 b.drain()
                 pend = None
+            f = b.follower
+            spec = f is not None and f[0].pending is None and f[0] is not b
+            if spec and b.n_at_bind < f[0].n_at_bind:
+                # the longer list's round is begun first; the shorter one's few small kernels go ahead of its waiting
+                # workgroups on a high-priority stream (SDPCUT_OPT_STREAM_PRIORITY), so this call still returns early
+                if not b.prioritised:
+                    b.drain()
+                    b.scorer.set_option(_capi.OPT_STREAM_PRIORITY, 1)
+                    b.prioritised, pend = True, None
+                f[0].begin(1, f[1], vv, _capi.EIG)
+                spec = False
             if pend is None:
                 b.begin(strat, head, vv, flags)
-            f = b.follower
-            if f is not None and f[0].pending is None and f[0] is not b:
+            if spec:
                 f[0].begin(1, f[1], vv, _capi.EIG)
             fused = b.end()
             idx, score = fused["idx"].copy(), fused["score"].copy()
