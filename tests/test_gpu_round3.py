@@ -458,6 +458,19 @@ def test_round_csr_in_two_halves_on_two_handles(pkg):
         assert b.pending is None and np.array_equal(got[:, :3], S2[:7, :3]) and not b.drop_pending()
         again = b.round_csr(1, 100, point=vv, copy=True)
         assert again["idx"].shape[0] == 100
+        # SDPCUT_OPT_STREAM_PRIORITY: the handle's stream re-created at the device's highest priority -- refused while a round
+        # is pending, same results afterwards (and back)
+        from sdpcutsel_via_nn_amd import _capi
+        b.round_csr_begin(1, 100, point=vv)
+        with pytest.raises(pkg.SdpCutError):
+            b.set_option(_capi.OPT_STREAM_PRIORITY, 1)
+        b.round_csr_end()
+        for prio in (1, 0):
+            b.set_option(_capi.OPT_STREAM_PRIORITY, prio)
+            a.round_csr_begin(4, 5000, point=vv)
+            b.round_csr_begin(1, 100, point=vv)
+            ra, rb = a.round_csr_end(copy=True), b.round_csr_end(copy=True)
+            assert all(np.array_equal(rb[f], again[f]) for f in fields) and ra["idx"].shape[0] == 5000
     finally:
         a.close()
         b.close()
