@@ -210,6 +210,11 @@ int sdpcut_destroy(sdpcut_handle h)
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
     hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 3; ++i) {
+        if (h->side_stream[i]) hipStreamDestroy(h->side_stream[i]);
+        if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return SDPCUT_OK;
@@ -241,6 +246,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         return SDPCUT_OK;
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
+        return SDPCUT_OK;
+    case SDPCUT_OPT_SIDE_STREAMS:
+        h->side_streams = value != 0;
         return SDPCUT_OK;
     case SDPCUT_OPT_STREAM_PRIORITY: {
         SDPCUT_NO_PENDING(h);

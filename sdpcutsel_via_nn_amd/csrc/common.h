@@ -70,6 +70,10 @@ struct PendingRound {
 struct sdpcut_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // the small size classes of a mixed cover are scored on side streams next to the largest one (launch_score)
+    bool side_streams = true;
+    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::string err;
     int kernel_variant = SDPCUT_KERNEL_MFMA;
     bool fuse_keys = true;         // SDPCUT_OPT_FUSE_KEYS (see include/sdpcut.h)

@@ -1084,9 +1084,9 @@ static int grid_for(sdpcut_ctx *h, int64_t ntiles, int per_cu)
 #define SCORE_LAUNCH(kern, grid, block)                                                              \
     do {                                                                                             \
         if (ev_start || ev_stop)                                                                     \
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, ev_start, ev_stop, 0, A); \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, ev_start, ev_stop, 0, A);       \
         else                                                                                         \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, A);                      \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, A);                             \
     } while (0)
 
 // does size class K run on the MFMA / VALU kernels (network shape they are instantiated for)?
@@ -1101,10 +1101,11 @@ static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
 
 template <int K>
 static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
-                          const ScoreFuse *fuse, int64_t *strong_out)
+                          const ScoreFuse *fuse, int64_t *strong_out, hipStream_t st = nullptr)
 {
     const Bucket &b = h->bucket[K];
     if (b.n == 0) return 0;
+    if (!st) st = h->stream;
     ScoreArgs A;
     A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
     A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
@@ -1160,6 +1161,17 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     return 0;
 }
 
+static int ensure_side_streams(sdpcut_ctx *h)
+{
+    if (h->ev_fork) return 0;
+    for (int i = 0; i < 3; ++i) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    return 0;
+}
+
 int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused, int64_t *strong_out)
 {
     // the histograms are built by the MFMA kernel only: every non-empty size class must run on it
@@ -1183,12 +1195,49 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
         h->timed_score = h->timing != 0 && h->N > 0;
         return launch_eig_only(h, fuse ? fuse->ws : nullptr, h->timed_score ? h->ev[0] : nullptr, h->timed_score ? h->ev[1] : nullptr);
     }
+    int nclasses = 0, kbig = 0;
     for (int k = 2; k <= SDPCUT_MAX_K; ++k)
-        if (h->bucket[k].n > 0) { if (!first) first = k; last = k; }
+        if (h->bucket[k].n > 0) {
+            if (!first) first = k;
+            last = k;
+            ++nclasses;
+            if (!kbig || h->bucket[k].n > h->bucket[kbig].n) kbig = k;
+        }
     h->timed_score = h->timing && first;
+    int rc;
+    if (nclasses > 1 && !h->timed_score && h->side_streams) {
+        // Several size classes: real covers hold one large class and a few sets of the smaller sizes (spar100-050-1, dim 5:
+        // 72 673 five-variable sets, 103 of four, 1 of three), and a launch over a hundred candidates costs what one tile costs
+        // -- 45-55 us of dependent stages -- however few they are.  One after the other on one stream that was 85 of the 256 us
+        // of a combined round on that cover.  The small classes go to side streams between a fork and a join event; the
+        // largest stays on the handle's stream.  (Scores land in disjoint slots, the histograms are atomics: no order needed.)
+        rc = ensure_side_streams(h);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+        // (the large class first: its launch is what the round waits for)
+        rc = kbig == 2 ? launch_score_k<2>(h, flags, nullptr, nullptr, fuse, strong_out)
+           : kbig == 3 ? launch_score_k<3>(h, flags, nullptr, nullptr, fuse, strong_out)
+           : kbig == 4 ? launch_score_k<4>(h, flags, nullptr, nullptr, fuse, strong_out)
+                       : launch_score_k<5>(h, flags, nullptr, nullptr, fuse, strong_out);
+        if (rc) return rc;
+        int side = 0;
+        for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
+            if (k == kbig || h->bucket[k].n == 0) continue;
+            hipStream_t st = h->side_stream[side];
+            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_fork, 0));
+            rc = k == 2 ? launch_score_k<2>(h, flags, nullptr, nullptr, fuse, strong_out, st)
+               : k == 3 ? launch_score_k<3>(h, flags, nullptr, nullptr, fuse, strong_out, st)
+               : k == 4 ? launch_score_k<4>(h, flags, nullptr, nullptr, fuse, strong_out, st)
+                        : launch_score_k<5>(h, flags, nullptr, nullptr, fuse, strong_out, st);
+            if (rc) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_join[side], st));
+            ++side;
+        }
+        for (int i = 0; i < side; ++i) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+        return 0;
+    }
     hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
     if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
-    int rc;
     if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, strong_out))) return rc;
     if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, strong_out))) return rc;
     if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, strong_out))) return rc;
