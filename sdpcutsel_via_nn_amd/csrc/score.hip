@@ -19,6 +19,8 @@
 // MFMA) exists for cross-checking and A/B timing (SDPCUT_KERNEL_SIMPLE).
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "jacobi.h"
 #include "gather.h"
@@ -30,6 +32,10 @@ struct ScoreArgs {
     const int32_t *set;   // SoA [K][n]
     const int32_t *orig;  // [n]
     int64_t n;
+    // score_mfma_kernel: the list in units of 16 candidates (one MFMA column tile), handed out in quanta of units_q units: wave g of
+    // the launch takes units_base (+1 if g < units_rem) consecutive quanta (launch_score_k)
+    int64_t units_base, units_rem;
+    int32_t units_q;
     const double *vars;   // [L + nv]: X packed | x
     const double *Q;      // [L]
     int32_t nv;
@@ -437,8 +443,8 @@ __device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], c
 #endif
 constexpr int mfma_cols(int K) { return K == 2 ? SDPCUT_MFMA_J_K2 : K == 3 ? SDPCUT_MFMA_J_K3 : K == 4 ? SDPCUT_MFMA_J_K4 : SDPCUT_MFMA_J_K5; }
 
-template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true, int J = 2>
-__global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void score_mfma_kernel(ScoreArgs A)
+template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true, int JK = 2>
+__global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void score_mfma_kernel(ScoreArgs A)
 {
     constexpr int M = K * (K + 1) / 2;
     constexpr int DIN = K + M;
@@ -449,30 +455,44 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
     // per k-step for 1/8 of the work: those rows run on the VALU instead (tail_rows below).
     constexpr int NT = (H - 16 * (T - 1) <= 4) ? H - 16 * (T - 1) : 0;
     constexpr int TM = NT ? T - 1 : T;     // row tiles computed with MFMA
-    constexpr int NPASS = 64 / (16 * J);   // passes of J 16-candidate column tiles over the wave's strip
-    static_assert(J == 1 || J == 2, "one or two column tiles per pass");
+    static_assert(JK == 1 || JK == 2, "one or two column tiles per pass");
     static_assert(T == 4, "hidden width must be in 49..64");
 
     __shared__ double feat[4][S0 * 4][64];  // per wave: feature-major strip of 64 candidates
     __shared__ double ynn[4][64];           // per wave: raw network outputs
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (wave-uniform by construction; said so to the compiler: the wave's range, its strip loop and pass counts are then scalar)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int q = lane >> 4;      // MFMA k-slot / output row group
     const int c16 = lane & 15;    // MFMA column (candidate within a 16-tile)
     const NetDev &net = A.net;
-    const int64_t ntiles = (A.n + 255) / 256;
+    // Work split (r3).  The list is cut into units of 16 candidates (one MFMA column tile); every wave of the launch takes a
+    // contiguous run of quanta of units_q units, equal to within one quantum, and walks it in strips of 64 candidates; a strip of
+    // fewer than four units runs one two-tile pass less and / or a final pass over a single column tile (mlp_pass<1>: the same
+    // arithmetic per candidate, bit-equal scores).
+    //  * Long lists: quanta of 4 units = whole strips, as many workgroups as eight per CU (short-lived: the dispatcher balances them).
+    //  * Lists that leave the device part-empty (<= 2 units per resident wave, i.e. <= 65 536 candidates -- most real covers):
+    //    quanta of 2 units, ONE pass per wave.  A launch over such a list takes as long as its slowest wave -- phase A plus its
+    //    passes, 45-95 us of dependent stages -- and twice as many waves with one pass each finish sooner than half as many with two.
+    //    (Finer than a pass does not pay: a single-tile pass of a lone wave takes as long as a two-tile pass,
+    //    profiles/r03_k3_kernel_time_vs_list_length.txt.)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t u_lo = A.units_q * (gw * A.units_base + (gw < A.units_rem ? gw : A.units_rem));
+    const int64_t u_n = A.units_q * (A.units_base + (gw < A.units_rem ? 1 : 0));
+    const int64_t c_lo = 16 * u_lo < A.n ? 16 * u_lo : A.n;
+    const int64_t c_hi = 16 * (u_lo + u_n) < A.n ? 16 * (u_lo + u_n) : A.n;
 
-    // The index set (and the output slot) of the NEXT tile are requested before phase B of the
+    // The index set (and the output slot) of the NEXT strip are requested before phase B of the
     // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
     // L2: the gathers they address) is off the critical path.
-    // (The first tile's request goes out before the LDS preload below so that the two latencies of a
+    // (The first strip's request goes out before the LDS preload below so that the two latencies of a
     // workgroup's start overlap.)
     int32_t s_nxt[K];
     int32_t orig_nxt = 0;
-    if ((int64_t)blockIdx.x < ntiles) {
-        const int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const int64_t cc0 = c0 < A.n ? c0 : A.n - 1;
+    if (c_lo < c_hi) {
+        const int64_t c0 = c_lo + lane;
+        const int64_t cc0 = c0 < c_hi ? c0 : c_hi - 1;
         load_index_set<K>(s_nxt, A.set, A.n, cc0);
         orig_nxt = A.orig[cc0];
     }
@@ -501,10 +521,10 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
     }
 
     PHASE_DECL;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t s0 = c_lo; s0 < c_hi; s0 += 64) {
         PHASE_MARK(0);
-        const int64_t c = tile * 256 + threadIdx.x;
-        const bool valid = c < A.n;
+        const int64_t c = s0 + lane;
+        const bool valid = c < c_hi;
         int32_t s_cur[K];
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
@@ -512,10 +532,10 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
         Cand<K> cd;
         gather_candidate<K>(cd, s_cur, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
         {
-            const int64_t tn = tile + gridDim.x;
-            if (tn < ntiles) {               // uniform
-                const int64_t c1 = tn * 256 + threadIdx.x;
-                const int64_t cc1 = c1 < A.n ? c1 : A.n - 1;
+            const int64_t sn = s0 + 64;
+            if (sn < c_hi) {                 // uniform per wave
+                const int64_t c1 = sn + lane;
+                const int64_t cc1 = c1 < c_hi ? c1 : c_hi - 1;
                 load_index_set<K>(s_nxt, A.set, A.n, cc1);
                 orig_nxt = A.orig[cc1];
             }
@@ -575,14 +595,15 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
 #pragma unroll
             for (int s = 0; s < S0; ++s) a_in[s] = net.wfrag[s * 64 + lane];
         }
-#pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {
+        // one pass of the MLP over JJ column tiles (16 JJ candidates from column col0 of the wave's strip)
+        auto mlp_pass = [&](auto jj_tag, const int col0) __attribute__((always_inline)) {
+            constexpr int J = decltype(jj_tag)::value;
             // B fragments of the input layer: B[k = 4s + q][col = candidate]
             double bin[S0][J];
 #pragma unroll
             for (int s = 0; s < S0; ++s)
 #pragma unroll
-                for (int j = 0; j < J; ++j) bin[s][j] = feat[wave][4 * s + q][16 * J * pass + 16 * j + c16];
+                for (int j = 0; j < J; ++j) bin[s][j] = feat[wave][4 * s + q][col0 + 16 * j + c16];
 
             d4 prev[T][J], cur[T][J];
             const double *wf = net.wfrag;
@@ -718,7 +739,22 @@ __global__ __launch_bounds__(256, (J == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void scor
                         if (16 * t + 4 * r < H) part = fma(cur[t][j][r], WOUT_AT(16 * t + 4 * r + q), part);
                 part = xor_add16(part);
                 part = xor_add32(part);
-                if (q == 0) ynn[wave][16 * J * pass + 16 * j + c16] = part;
+                if (q == 0) ynn[wave][col0 + 16 * j + c16] = part;
+            }
+        };
+        {
+            const int units = (int)(((c_hi - s0 < 64 ? c_hi - s0 : 64) + 15) >> 4);      // column tiles of this strip that hold candidates
+            // (a whole strip has its own loop with a constant trip count, and the rare paths are marked so: with one generic loop
+            // the 5-variable kernel ran 1.5 % slower than before the split, this way 0.8 %, the 3- and 4-variable ones 1 % faster)
+            if (__builtin_expect(units == 4, 1)) {
+#pragma unroll 1
+                for (int pass = 0; pass < 4 / JK; ++pass) mlp_pass(std::integral_constant<int, JK>{}, 16 * JK * pass);
+            } else {
+#pragma unroll 1
+                for (int pass = 0; pass < units / JK; ++pass) mlp_pass(std::integral_constant<int, JK>{}, 16 * JK * pass);
+                if constexpr (JK == 2) {
+                    if (units & 1) mlp_pass(std::integral_constant<int, 1>{}, 16 * (units - 1));
+                }
             }
         }
         wave_lds_sync();
@@ -1108,6 +1144,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     if (!st) st = h->stream;
     ScoreArgs A;
     A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
+    A.units_base = A.units_rem = 0; A.units_q = 4;
     A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
@@ -1126,7 +1163,17 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         if (K == 5) SCORE_LAUNCH((score_valu_kernel<5, 64, 4>), grid, 256);
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
-        const int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
+        int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
+        {   // quanta of units over the 4 * grid waves of the launch, equal to within one (see the kernel)
+            const int64_t units = (b.n + 15) / 16, resident_waves = (int64_t)h->n_cu * 4 * 2;
+            if (units <= 2 * resident_waves) {      // part-empty device: one two-tile pass per wave
+                A.units_q = 2;
+                grid = (int)(((units + 1) / 2 + 3) / 4);
+            }
+            const int64_t quanta = (units + A.units_q - 1) / A.units_q, waves = 4 * (int64_t)grid;
+            A.units_base = quanta / waves;
+            A.units_rem = quanta % waves;
+        }
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
