@@ -280,6 +280,49 @@ def bench_c5(device_index, steps, warm=10):
     return out
 
 
+MIXED_GOLDENS = ("rounds_spar100_050_1_d5_s4.npz", "rounds_spar070_050_1_d5_s4.npz")
+
+
+def bench_mixed_cover(device_index, steps):
+    """us per fused round (sdpcut_round_csr) on real covers with several size classes, shorter than the device is wide --
+    the paper's dim-5 runs (generate_figs_tables.py:529-534): spar100-050-1 (72 673 five-, 103 four-, 1 three-variable sets) and
+    spar070-050-1 (10 777 sets), enumerated on the device, at the LP points the reference's own trajectories recorded for round 2
+    (combined strategy) and round 9 (feasibility); with the small classes on side streams and one launch after the other."""
+    import torch
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, harness
+    import gc
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    gc.collect()
+    gc.freeze()      # (a generation-2 collection inside one of the short timed loops below would be most of its time)
+    for fn in MIXED_GOLDENS:
+        g = np.load(os.path.join(gold, fn))
+        name, dim, sel = str(g["name"]), int(g["dim"]), int(g["sel_size"])
+        inst = harness.parse_boxqp(os.path.join(gold, "instances", name + ".in"))
+        sc = pkg.Scorer(device_index)
+        sc.set_builtin_networks(dim)
+        sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+        N = sc.set_candidates_cover(inst["adj"], dim)
+        _, ks = sc.get_candidates(np.arange(N))
+        rec = {"candidates": N, "sizes_2_to_5": np.bincount(ks, minlength=6)[2:].tolist(), "sel_size": sel, "steps": steps}
+        for r in (2, 9):
+            vv, strat = np.ascontiguousarray(g["r%02d_vars" % r]), int(g["r%02d_strat" % r])
+            for side in (2, 0):      # 2: the library's default (measured once per list), 0: one launch after the other
+                sc.set_option(_capi.OPT_SIDE_STREAMS, side)
+                for _ in range(30):
+                    sc.round_csr(strat, sel, point=vv)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    res = sc.round_csr(strat, sel, point=vv)
+                us = (time.perf_counter() - t0) / steps * 1e6
+                rec["round_%d_strategy_%d%s" % (r, strat, "" if side else "_classes_one_after_the_other")] = {"round_us": us, "cuts": int(res["rhs"].shape[0])}
+        sc.close()
+        out[name + "_dim%d" % dim] = rec
+    return out
+
+
 def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     """the feasibility round (strategy 1) on the main workload: eigenvalue-only kernel + selection + rows"""
     import torch
@@ -627,6 +670,7 @@ def main():
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))
+                out["secondary"]["mixed_cover"] = bench_mixed_cover(local_rank, max(50, args.steps // 2))
         if world == 1 and not args.no_cpu_baseline:
             vv_host = np.array(vv_host)     # (detach from the handle's pinned buffer: worker processes pickle it)
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample

@@ -80,8 +80,10 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
 /* SDPCUT_OPT_EIG_KERNEL (default 1): launches that compute only lambda_min (feasibility rounds,
  * cut_select_qp.py:639-654) run the dedicated eigenvalue kernel -- one launch over all size classes, compiled
  * without the MLP's register state -- instead of the scoring kernels' eigenvalue branch (0: A/B). */
-/* SDPCUT_OPT_SIDE_STREAMS (default 1): a list with several size classes scores its smaller classes on side streams of the handle,
- * between a fork and a join event, next to the largest class on the handle's stream (0: one launch after the other, A/B). */
+/* SDPCUT_OPT_SIDE_STREAMS (default 2): a list with several size classes may score its smaller classes on side streams of the handle,
+ * between a fork and a join event, next to the largest class on the handle's stream.  0: one launch after the other; 1: side
+ * streams; 2: the first multi-class scoring of a candidate list measures both forms (~1 ms, once) and keeps the faster --
+ * whether the streams run side by side depends on which hardware queues the process's streams were given. */
 /* SDPCUT_OPT_STREAM_PRIORITY (default 0): 1 re-creates the handle's own stream with the device's highest priority.  For a handle
  * whose list is SHORT and whose rounds run next to another handle's (the QCQP round's objective cover beside its constraints
  * cover, sdpcut_round_csr_begin): its few small kernels are then dispatched ahead of the other list's waiting workgroups instead of

@@ -148,6 +148,7 @@ static void free_candidates(sdpcut_ctx *h)
     hipFree(h->d_set_orig); hipFree(h->d_k); hipFree(h->d_eig); hipFree(h->d_obj);
     h->d_set_orig = nullptr; h->d_k = nullptr; h->d_eig = nullptr; h->d_obj = nullptr;
     h->N = 0; h->scored = 0; h->last_total = -1;
+    h->side_choice = -1;      // (a new list measures for itself whether its small size classes go to side streams)
 }
 
 // Scores of a round's selection (strategy strat, head of `cap` entries), not computed yet at this point:
@@ -248,7 +249,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
     case SDPCUT_OPT_SIDE_STREAMS:
-        h->side_streams = value != 0;
+        if (value < 0 || value > 2) return sdpcut_fail(h, SDPCUT_EINVAL, "SDPCUT_OPT_SIDE_STREAMS: 0 off, 1 on, 2 measured");
+        h->side_streams = (int)value;
+        h->side_choice = -1;
         return SDPCUT_OK;
     case SDPCUT_OPT_STREAM_PRIORITY: {
         SDPCUT_NO_PENDING(h);

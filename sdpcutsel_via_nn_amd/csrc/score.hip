@@ -1211,11 +1211,91 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
 static int ensure_side_streams(sdpcut_ctx *h)
 {
     if (h->ev_fork) return 0;
+    // at the device's highest priority: the runtime keeps separate hardware queues per priority level, so the side streams do not
+    // land in the queue of the handle's own (normal-priority) stream however many streams the process has created before -- in
+    // a process that also runs torch they did, and the classes ran one after the other again, plus the events -- and their few
+    // workgroups are dispatched ahead of the large class's waiting ones
+    int least = 0, greatest = 0;
+    HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
     for (int i = 0; i < 3; ++i) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream[i], hipStreamNonBlocking, greatest));
         HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
     }
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    return 0;
+}
+
+static int launch_score_any(sdpcut_ctx *h, int k, uint32_t flags, hipEvent_t es, hipEvent_t ee, const ScoreFuse *fuse, int64_t *strong_out,
+                            hipStream_t st)
+{
+    return k == 2 ? launch_score_k<2>(h, flags, es, ee, fuse, strong_out, st)
+         : k == 3 ? launch_score_k<3>(h, flags, es, ee, fuse, strong_out, st)
+         : k == 4 ? launch_score_k<4>(h, flags, es, ee, fuse, strong_out, st)
+                  : launch_score_k<5>(h, flags, es, ee, fuse, strong_out, st);
+}
+
+// the size classes one launch after the other on the handle's stream
+static int launch_classes_seq(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, int64_t *strong_out, const hipEvent_t *es,
+                              const hipEvent_t *ee)
+{
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
+        const int rc = launch_score_any(h, k, flags, es ? es[k] : nullptr, ee ? ee[k] : nullptr, fuse, strong_out, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Several size classes: real covers hold one large class and a few sets of the smaller sizes (spar100-050-1, dim 5: 72 673
+// five-variable sets, 103 of four, 1 of three), and a launch over a hundred candidates costs what one pass costs -- 25-55 us of
+// dependent stages -- however few they are.  Here the small classes go to side streams between a fork and a join event, the
+// largest first on the handle's stream (its launch is what the round waits for).  Scores land in disjoint slots, the
+// histograms are atomics: no order is needed.
+static int launch_classes_side(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, int64_t *strong_out, int kbig)
+{
+    int rc = ensure_side_streams(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    if ((rc = launch_score_any(h, kbig, flags, nullptr, nullptr, fuse, strong_out, nullptr))) return rc;
+    int side = 0;
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
+        if (k == kbig || h->bucket[k].n == 0) continue;
+        hipStream_t st = h->side_stream[side];
+        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_fork, 0));
+        if ((rc = launch_score_any(h, k, flags, nullptr, nullptr, fuse, strong_out, st))) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev_join[side], st));
+        ++side;
+    }
+    for (int i = 0; i < side; ++i) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+    return 0;
+}
+
+// Whether the side streams pay is a property of the process, not of the list: streams share a few hardware queues, assigned as
+// they are created, and a side stream that lands in the queue of the handle's own stream runs its class BEHIND the large one --
+// 193 instead of 154 us per round on spar070-050-1 in one process, 141 in another (profiles/r03_mixed_cover_round_timeline.txt).
+// So the first multi-class scoring of a candidate list measures both forms (three plain scoring passes each, no histograms,
+// the same scores written six times: ~1 ms once per list) and keeps the faster.
+static int calibrate_side_streams(sdpcut_ctx *h, uint32_t flags, int kbig)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    float best[2] = {1e30f, 1e30f};
+    int rc = 0;
+    for (int rep = 0; rep < 3 && !rc; ++rep)
+        for (int form = 0; form < 2 && !rc; ++form) {
+            (void)hipEventRecord(e0, h->stream);
+            rc = form ? launch_classes_side(h, flags, nullptr, nullptr, kbig) : launch_classes_seq(h, flags, nullptr, nullptr, nullptr, nullptr);
+            (void)hipEventRecord(e1, h->stream);
+            if (!rc && hipEventSynchronize(e1) != hipSuccess) rc = sdpcut_fail(h, SDPCUT_EHIP, "side-stream calibration failed");
+            float ms = 0.f;
+            if (!rc && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best[form]) best[form] = ms;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    h->side_choice = best[1] < 0.97f * best[0] ? 1 : 0;
+    h->side_ms[0] = best[0];
+    h->side_ms[1] = best[1];
     return 0;
 }
 
@@ -1253,43 +1333,12 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
     h->timed_score = h->timing && first;
     int rc;
     if (nclasses > 1 && !h->timed_score && h->side_streams) {
-        // Several size classes: real covers hold one large class and a few sets of the smaller sizes (spar100-050-1, dim 5:
-        // 72 673 five-variable sets, 103 of four, 1 of three), and a launch over a hundred candidates costs what one tile costs
-        // -- 45-55 us of dependent stages -- however few they are.  One after the other on one stream that was 85 of the 256 us
-        // of a combined round on that cover.  The small classes go to side streams between a fork and a join event; the
-        // largest stays on the handle's stream.  (Scores land in disjoint slots, the histograms are atomics: no order needed.)
-        rc = ensure_side_streams(h);
-        if (rc) return rc;
-        HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
-        // (the large class first: its launch is what the round waits for)
-        rc = kbig == 2 ? launch_score_k<2>(h, flags, nullptr, nullptr, fuse, strong_out)
-           : kbig == 3 ? launch_score_k<3>(h, flags, nullptr, nullptr, fuse, strong_out)
-           : kbig == 4 ? launch_score_k<4>(h, flags, nullptr, nullptr, fuse, strong_out)
-                       : launch_score_k<5>(h, flags, nullptr, nullptr, fuse, strong_out);
-        if (rc) return rc;
-        int side = 0;
-        for (int k = 2; k <= SDPCUT_MAX_K; ++k) {
-            if (k == kbig || h->bucket[k].n == 0) continue;
-            hipStream_t st = h->side_stream[side];
-            HIP_TRY(h, hipStreamWaitEvent(st, h->ev_fork, 0));
-            rc = k == 2 ? launch_score_k<2>(h, flags, nullptr, nullptr, fuse, strong_out, st)
-               : k == 3 ? launch_score_k<3>(h, flags, nullptr, nullptr, fuse, strong_out, st)
-               : k == 4 ? launch_score_k<4>(h, flags, nullptr, nullptr, fuse, strong_out, st)
-                        : launch_score_k<5>(h, flags, nullptr, nullptr, fuse, strong_out, st);
-            if (rc) return rc;
-            HIP_TRY(h, hipEventRecord(h->ev_join[side], st));
-            ++side;
-        }
-        for (int i = 0; i < side; ++i) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
-        return 0;
+        if (h->side_streams == 2 && h->side_choice < 0 && (rc = calibrate_side_streams(h, flags, kbig))) return rc;
+        if (h->side_streams == 1 || h->side_choice == 1) return launch_classes_side(h, flags, fuse, strong_out, kbig);
     }
     hipEvent_t es[SDPCUT_MAX_K + 1] = {}, ee[SDPCUT_MAX_K + 1] = {};
     if (h->timed_score) { es[first] = h->ev[0]; ee[last] = h->ev[1]; }
-    if ((rc = launch_score_k<2>(h, flags, es[2], ee[2], fuse, strong_out))) return rc;
-    if ((rc = launch_score_k<3>(h, flags, es[3], ee[3], fuse, strong_out))) return rc;
-    if ((rc = launch_score_k<4>(h, flags, es[4], ee[4], fuse, strong_out))) return rc;
-    if ((rc = launch_score_k<5>(h, flags, es[5], ee[5], fuse, strong_out))) return rc;
-    return 0;
+    return launch_classes_seq(h, flags, fuse, strong_out, es, ee);
 }
 
 int launch_eig_batch(sdpcut_ctx *h, int k, int64_t count, const double *d_x, const double *d_X,

@@ -525,3 +525,43 @@ def test_qcqp_loop_begins_both_covers_rounds_together(pkg, oracle, golden_qcqp, 
     assert bc.wasted == 1 and bc.pending is None
     assert np.array_equal(got.ids(40), want.ids(40)) and np.array_equal(got.scores(40), want.scores(40))
     x._agg_list = y._agg_list = agg_o
+
+
+def test_small_size_classes_on_side_streams_give_the_same_round(pkg):
+    """SDPCUT_OPT_SIDE_STREAMS: a list with one large and several small size classes scored with the small classes on side streams
+    (1), one launch after the other (0) and with the form measured at first use (2, the default): the same round bit for bit,
+    also right after a new list and next to a second handle's round."""
+    from sdpcutsel_via_nn_amd import _capi
+    Q_arr, vv, S, ks = _mixed_workload(60, (5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 3, 2), 33000, seed=41)
+    a, b = pkg.Scorer(0), pkg.Scorer(0)
+    try:
+        for sc in (a, b):
+            sc.set_builtin_networks(5)
+            sc.set_instance(60, Q_arr)
+        a.set_candidates(S, ks)
+        b.set_candidates(S[:5000], ks[:5000])
+        fields = ("idx", "score", "lam", "row_entry", "indptr", "indices", "values", "rhs")
+        ref = {}
+        for mode in (0, 1, 2, 2):
+            a.set_option(_capi.OPT_SIDE_STREAMS, mode)
+            for strat in (4, 2, 1):
+                r = a.round_csr(strat, 3000, point=vv, copy=True)
+                if mode == 0:
+                    ref[strat] = r
+                else:
+                    assert all(np.array_equal(r[f], ref[strat][f]) for f in fields) and r["counters"] == ref[strat]["counters"], (mode, strat)
+        a.set_candidates(S[::-1].copy(), ks[::-1].copy())          # a new list measures again
+        r0 = a.round_csr(4, 3000, point=vv, copy=True)
+        a.set_option(_capi.OPT_SIDE_STREAMS, 0)
+        r1 = a.round_csr(4, 3000, point=vv, copy=True)
+        assert all(np.array_equal(r0[f], r1[f]) for f in fields)
+        a.set_option(_capi.OPT_SIDE_STREAMS, 1)
+        a.round_csr_begin(4, 3000, point=vv)
+        b.round_csr_begin(4, 500, point=vv)
+        r2, _ = a.round_csr_end(copy=True), b.round_csr_end()
+        assert all(np.array_equal(r2[f], r1[f]) for f in fields)
+        with pytest.raises(ValueError):
+            a.set_option(_capi.OPT_SIDE_STREAMS, 3)
+    finally:
+        a.close()
+        b.close()
