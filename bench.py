@@ -374,8 +374,8 @@ class _StdoutToStderr(object):
 # 10^6 candidates; a VALU instruction occupies its SIMD for 4 cycles, a quarter-rate transcendental for 16, an fp64 MFMA for 64):
 # what the kernel would take if its SIMDs never waited.  Not a roofline in the HBM / MFMA sense -- the bound these kernels run into.
 ISSUE_CYCLES_PER_CAND = {
-    ("eig", 3): ((18.64 - 1.26) * 4 + 1.26 * 16, "profiles/r03_eig_k3_kernel_pmc.txt"),
-    ("mfma", 3): ((5111 * 4 + 348 * 64) / 64.0, "profiles/r02b_k3_score_kernel_pmc.txt (5111 VALU + 348 MFMA per 64-candidate strip)"),
+    ("eig", 3): ((18.67 - 1.26) * 4 + 1.26 * 16, "profiles/r03_eig_k3_kernel_pmc.txt"),
+    ("mfma", 3): ((5357 * 4 + 348 * 64) / 64.0, "profiles/r03_k3_score_kernel_pmc.txt (83.71 M VALU + 5.4375 M MFMA per launch = 5357 + 348 per 64-candidate strip)"),
 }
 SIMDS, CLOCK_GHZ = 1024, 2.4
 
