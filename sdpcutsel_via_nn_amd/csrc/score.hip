@@ -32,10 +32,8 @@ struct ScoreArgs {
     const int32_t *set;   // SoA [K][n]
     const int32_t *orig;  // [n]
     int64_t n;
-    // score_mfma_kernel: the list in units of 16 candidates (one MFMA column tile), handed out in quanta of units_q units: wave g of
-    // the launch takes units_base (+1 if g < units_rem) consecutive quanta (launch_score_k)
-    int64_t units_base, units_rem;
-    int32_t units_q;
+    // score_mfma_kernel: candidates per strip of a wave, 64 or 32 (launch_score_k; see the kernel)
+    int32_t strip;
     const double *vars;   // [L + nv]: X packed | x
     const double *Q;      // [L]
     int32_t nv;
@@ -467,21 +465,20 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     const int q = lane >> 4;      // MFMA k-slot / output row group
     const int c16 = lane & 15;    // MFMA column (candidate within a 16-tile)
     const NetDev &net = A.net;
-    // Work split (r3).  The list is cut into units of 16 candidates (one MFMA column tile); every wave of the launch takes a
-    // contiguous run of quanta of units_q units, equal to within one quantum, and walks it in strips of 64 candidates; a strip of
-    // fewer than four units runs one two-tile pass less and / or a final pass over a single column tile (mlp_pass<1>: the same
-    // arithmetic per candidate, bit-equal scores).
-    //  * Long lists: quanta of 4 units = whole strips, as many workgroups as eight per CU (short-lived: the dispatcher balances them).
-    //  * Lists that leave the device part-empty (<= 2 units per resident wave, i.e. <= 65 536 candidates -- most real covers):
-    //    quanta of 2 units, ONE pass per wave.  A launch over such a list takes as long as its slowest wave -- phase A plus its
-    //    passes, 45-95 us of dependent stages -- and twice as many waves with one pass each finish sooner than half as many with two.
-    //    (Finer than a pass does not pay: a single-tile pass of a lone wave takes as long as a two-tile pass,
-    //    profiles/r03_k3_kernel_time_vs_list_length.txt.)
+    // Work split (r3).  The list is cut into STRIPS of A.strip candidates, and wave g of the launch takes strips g, g + W, g + 2W ...
+    // (W waves in the launch: the four waves of a workgroup take four consecutive strips, the workgroups move through the list
+    // together -- at 10^8 candidates that keeps the 3 GB of index sets and scores the resident waves touch close together).
+    //  * Long lists: strips of 64 candidates = two passes of the MLP over two 16-candidate column tiles each, eight workgroups per
+    //    CU (short-lived: the dispatcher balances them).
+    //  * Lists that leave the device part-empty (<= 32 candidates per resident wave, i.e. <= 65 536 -- most real covers): strips
+    //    of 32, ONE pass per wave.  A launch over such a list takes as long as its slowest wave -- phase A plus its passes, 45-95 us
+    //    of dependent stages -- and twice as many waves with one pass each finish sooner than half as many with two.  (Finer does
+    //    not pay: a single-tile pass of a lone wave takes as long as a two-tile pass, profiles/r03_k3_kernel_time_vs_list_length.txt.)
+    // The last strip of a list may hold fewer candidates: it runs the passes its column tiles need, the last one over a single
+    // tile if their number is odd (mlp_pass<1>: the same arithmetic per candidate, bit-equal scores).
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t u_lo = A.units_q * (gw * A.units_base + (gw < A.units_rem ? gw : A.units_rem));
-    const int64_t u_n = A.units_q * (A.units_base + (gw < A.units_rem ? 1 : 0));
-    const int64_t c_lo = 16 * u_lo < A.n ? 16 * u_lo : A.n;
-    const int64_t c_hi = 16 * (u_lo + u_n) < A.n ? 16 * (u_lo + u_n) : A.n;
+    const int64_t wstride = (int64_t)gridDim.x * 4 * A.strip;      // candidates between two strips of one wave
+    const int64_t c_first = gw * A.strip;
 
     // The index set (and the output slot) of the NEXT strip are requested before phase B of the
     // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
@@ -490,9 +487,9 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     // workgroup's start overlap.)
     int32_t s_nxt[K];
     int32_t orig_nxt = 0;
-    if (c_lo < c_hi) {
-        const int64_t c0 = c_lo + lane;
-        const int64_t cc0 = c0 < c_hi ? c0 : c_hi - 1;
+    if (c_first < A.n) {
+        const int64_t c0 = c_first + lane;
+        const int64_t cc0 = (c0 < A.n && lane < A.strip) ? c0 : c_first;
         load_index_set<K>(s_nxt, A.set, A.n, cc0);
         orig_nxt = A.orig[cc0];
     }
@@ -521,10 +518,10 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     }
 
     PHASE_DECL;
-    for (int64_t s0 = c_lo; s0 < c_hi; s0 += 64) {
+    for (int64_t s0 = c_first; s0 < A.n; s0 += wstride) {
         PHASE_MARK(0);
         const int64_t c = s0 + lane;
-        const bool valid = c < c_hi;
+        const bool valid = c < A.n && lane < A.strip;
         int32_t s_cur[K];
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
@@ -532,10 +529,10 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
         Cand<K> cd;
         gather_candidate<K>(cd, s_cur, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
         {
-            const int64_t sn = s0 + 64;
-            if (sn < c_hi) {                 // uniform per wave
+            const int64_t sn = s0 + wstride;
+            if (sn < A.n) {                  // uniform per wave
                 const int64_t c1 = sn + lane;
-                const int64_t cc1 = c1 < c_hi ? c1 : c_hi - 1;
+                const int64_t cc1 = (c1 < A.n && lane < A.strip) ? c1 : sn;
                 load_index_set<K>(s_nxt, A.set, A.n, cc1);
                 orig_nxt = A.orig[cc1];
             }
@@ -743,7 +740,7 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
             }
         };
         {
-            const int units = (int)(((c_hi - s0 < 64 ? c_hi - s0 : 64) + 15) >> 4);      // column tiles of this strip that hold candidates
+            const int units = (int)(((A.n - s0 < A.strip ? A.n - s0 : A.strip) + 15) >> 4);      // column tiles of this strip that hold candidates
             // (a whole strip has its own loop with a constant trip count, and the rare paths are marked so: with one generic loop
             // the 5-variable kernel ran 1.5 % slower than before the split, this way 0.8 %, the 3- and 4-variable ones 1 % faster)
             if (__builtin_expect(units == 4, 1)) {
@@ -1144,7 +1141,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     if (!st) st = h->stream;
     ScoreArgs A;
     A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
-    A.units_base = A.units_rem = 0; A.units_q = 4;
+    A.strip = 64;
     A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
@@ -1164,15 +1161,9 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     } else if (h->kernel_variant == SDPCUT_KERNEL_MFMA && mfma_ok) {
         const int64_t ntiles = (b.n + 255) / 256;
         int grid = grid_for(h, ntiles, SDPCUT_MFMA_BLOCKS_PER_CU);
-        {   // quanta of units over the 4 * grid waves of the launch, equal to within one (see the kernel)
-            const int64_t units = (b.n + 15) / 16, resident_waves = (int64_t)h->n_cu * 4 * 2;
-            if (units <= 2 * resident_waves) {      // part-empty device: one two-tile pass per wave
-                A.units_q = 2;
-                grid = (int)(((units + 1) / 2 + 3) / 4);
-            }
-            const int64_t quanta = (units + A.units_q - 1) / A.units_q, waves = 4 * (int64_t)grid;
-            A.units_base = quanta / waves;
-            A.units_rem = quanta % waves;
+        if (b.n <= 32 * (int64_t)h->n_cu * 4 * 2) {      // part-empty device: one two-tile pass per wave
+            A.strip = 32;
+            grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
