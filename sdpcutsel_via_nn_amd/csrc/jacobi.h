@@ -318,3 +318,122 @@ __device__ __forceinline__ void fill_lifted(double (&a)[K + 1][K + 1], const dou
             ++m;
         }
 }
+
+// ------------------------------------------------------------------------------------------
+// Eigenvector of a KNOWN smallest eigenvalue (r3): inverse iteration on B = A - lam I.
+//
+// The epilogue of a round needs the eigenvector of lambda_min for at most a few thousand head entries whose lambda_min
+// the scoring pass has already computed.  Jacobi with vectors is ~6700 instructions per 6x6 matrix, and an epilogue of
+// 5000 entries is 79 waves on 1024 SIMDs: one wave per SIMD issuing them one after the other -- 25 of the 35 us of
+// round_csr_kernel (tools/csr_abl.sh).  With lam known, B is singular to working precision and three solves with its LU
+// factors (partial pivoting, pivots below eps ||A|| replaced by eps ||A|| as LAPACK's dlaein does) turn any start vector
+// into the eigenvector: ~700 instructions.  Backward stable: the result satisfies ||A v - lam v|| <= a few ulp of ||A||
+// whatever the multiplicity of lam (for a multiple lambda_min it is SOME unit vector of the eigenspace, as LAPACK's and
+// Jacobi's are); its distance from LAPACK's eigenvector is eps / gap like any method's.  Row exchanges are selects over
+// compile-time indices (no scratch).  Returns the residual max |A v - lam v| / ||A|| -- or 1 if lam is a multiple eigenvalue (see
+// the end); the caller falls back to Jacobi if it is not tiny (for simple eigenvalues never observed: tests/test_gpu_round3.py, oracle prototype over 30 000 matrices incl. rank-one and vertex ones).
+template <int D>
+__device__ __forceinline__ double min_eigvec_known(const double (&a)[D][D], double lam, double (&v)[D])
+{
+    double m[D][D];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            scale = fmax(scale, fabs(a[i][j]));
+            m[i][j] = (i == j) ? a[i][j] - lam : a[i][j];
+        }
+    const double tiny = fmax(scale, 1e-290) * 2.220446049250313e-16;
+    int piv_row[D];
+    double rinv[D];
+    int nsmall = 0;      // pivots that are zero against ||A||: the dimension of the (numerical) null space of B
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (c < D - 1) {
+            int best = c;
+            double bv = fabs(m[c][c]);
+#pragma unroll
+            for (int r = c + 1; r < D; ++r) {
+                const double t = fabs(m[r][c]);
+                const bool g = t > bv;
+                bv = g ? t : bv;
+                best = g ? r : best;
+            }
+            piv_row[c] = best;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {      // exchange rows c and best (multipliers of earlier columns included)
+                const double mc = m[c][j];
+                double mb = mc;
+#pragma unroll
+                for (int r = c + 1; r < D; ++r) mb = (best == r) ? m[r][j] : mb;
+#pragma unroll
+                for (int r = c + 1; r < D; ++r) m[r][j] = (best == r) ? mc : m[r][j];
+                m[c][j] = mb;
+            }
+        }
+        double p = m[c][c];
+        nsmall += fabs(p) < 1e-10 * scale;
+        p = fabs(p) < tiny ? copysign(tiny, p) : p;
+        rinv[c] = jac_rcp(p);
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            const double l = m[r][c] * rinv[c];
+            m[r][c] = l;
+#pragma unroll
+            for (int j = c + 1; j < D; ++j) m[r][j] = fma(-l, m[c][j], m[r][j]);
+        }
+    }
+    double b[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) b[i] = 1.0 + 0.37 * i;      // (not orthogonal to the structured eigenvectors of vertex matrices)
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+#pragma unroll
+        for (int c = 0; c < D - 1; ++c) {      // P b
+            const double bc = b[c];
+            double bb = bc;
+#pragma unroll
+            for (int r = c + 1; r < D; ++r) bb = (piv_row[c] == r) ? b[r] : bb;
+#pragma unroll
+            for (int r = c + 1; r < D; ++r) b[r] = (piv_row[c] == r) ? bc : b[r];
+            b[c] = bb;
+        }
+#pragma unroll
+        for (int c = 0; c < D - 1; ++c)        // L y = P b
+#pragma unroll
+            for (int r = c + 1; r < D; ++r) b[r] = fma(-m[r][c], b[c], b[r]);
+#pragma unroll
+        for (int r = D - 1; r >= 0; --r) {     // U x = y
+            double s = b[r];
+#pragma unroll
+            for (int j = r + 1; j < D; ++j) s = fma(-m[r][j], b[j], s);
+            b[r] = s * rinv[r];
+        }
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mx = fmax(mx, fabs(b[i]));
+        const double sc = jac_rcp(fmax(mx, 1e-290));      // keep the iterate O(1): it grows by 1/eps per solve
+#pragma unroll
+        for (int i = 0; i < D; ++i) b[i] *= sc;
+    }
+    double nn = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) nn = fma(b[i], b[i], nn);
+    const double rn = jac_rsqrt_any(nn);
+#pragma unroll
+    for (int i = 0; i < D; ++i) v[i] = b[i] * rn;
+    double res = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = -lam * v[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) s = fma(a[i][j], v[j], s);
+        res = fmax(res, fabs(s));
+    }
+    // A multiple (or 1e-10-close) lambda_min has no eigenVECTOR, only an eigenspace, and which of its unit vectors a method returns
+    // is the method's own business: at the structured first vertex of the QCQP instances Jacobi's choice tracks LAPACK's closely
+    // enough for the bounds of the first rounds to agree to 1e-6, a generic vector of the plane does not (0.4 % after two rounds
+    // on q_50_25_75_1).  Such matrices are left to Jacobi.
+    return nsmall >= 2 ? 1.0 : res / fmax(scale, 1.0);
+}

@@ -20,7 +20,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // Eigen-cut rows of selected candidates (cut_select_qp.py:737-750), one lane per cut.
 template <int K>
 __device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *vars, int32_t nv, int64_t L,
-                                            double *lam_out, double *coef, double *rhs, int64_t *cols)
+                                            double *lam_out, double *coef, double *rhs, int64_t *cols, const double *lam_known = nullptr)
 {
     constexpr int M = K * (K + 1) / 2;
     constexpr int D = K + 1;
@@ -45,20 +45,37 @@ __device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *var
             }
         }
     }
-    double a[D][D], v[D][D];
+    double a[D][D];
     fill_lifted<K>(a, x, X);
-    jacobi_eig<D, true>(a, v);
-    // eigenvector of the smallest eigenvalue (first minimum, like LAPACK's ascending order)
-    double lam = a[0][0];
+    double lam = 0.0;
     double ev[D];
+    bool have = false;
+#ifndef SDPCUT_ROWS_INVERSE_ITERATION
+#define SDPCUT_ROWS_INVERSE_ITERATION 1
+#endif
+    if (SDPCUT_ROWS_INVERSE_ITERATION && lam_known) {
+        // the scoring pass has computed lambda_min of this candidate (the value the selection ranked by): its eigenvector by
+        // inverse iteration (jacobi.h: ~700 instead of ~6700 instructions of a wave that has its SIMD to itself)
+        lam = *lam_known;
+        have = min_eigvec_known<D>(a, lam, ev) <= 1e-12;
+#ifdef SDPCUT_ABL_NOFALLBACK      // timing experiment (tools/build_ablation.sh, ABL_SRC=rows): wrong on multiple eigenvalues
+        have = true;
+#endif
+    }
+    if (!have) {      // no lambda_min at hand (optimality rounds, explicit sdpcut_cut_rows) -- or, never observed, a residual too large
+        double v[D][D];
+        jacobi_eig<D, true>(a, v);
+        // eigenvector of the smallest eigenvalue (first minimum, like LAPACK's ascending order)
+        lam = a[0][0];
 #pragma unroll
-    for (int i = 0; i < D; ++i) ev[i] = v[i][0];
+        for (int i = 0; i < D; ++i) ev[i] = v[i][0];
 #pragma unroll
-    for (int j = 1; j < D; ++j) {
-        const bool less = a[j][j] < lam;
-        lam = less ? a[j][j] : lam;
+        for (int j = 1; j < D; ++j) {
+            const bool less = a[j][j] < lam;
+            lam = less ? a[j][j] : lam;
 #pragma unroll
-        for (int i = 0; i < D; ++i) ev[i] = less ? v[i][j] : ev[i];
+            for (int i = 0; i < D; ++i) ev[i] = less ? v[i][j] : ev[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < D; ++i) ev[i] = (fabs(ev[i]) <= -SDPCUT_NEG_EIGVAL) ? 0.0 : ev[i];  // :744
@@ -84,7 +101,7 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
                                                       const int32_t *ks,
                                                       const double *vars, int32_t nv, int64_t L, double *lam,
                                                       double *coef, int coef_ld, double *rhs, int64_t *cols,
-                                                      int32_t *ks_out)
+                                                      int32_t *ks_out, const double *eig)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (d_limit && *d_limit < count) count = *d_limit;
@@ -107,10 +124,10 @@ __global__ __launch_bounds__(64) void cut_rows_kernel(int64_t count, const int64
     for (int m = 0; m < SDPCUT_ROW_LD; ++m) { co[m] = 0.0; cl[m] = -1; }
     ks_out[i] = k;
     switch (k) {
-    case 2: cut_row_one<2>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    case 3: cut_row_one<3>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    case 4: cut_row_one<4>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
-    default: cut_row_one<5>(s5, vars, nv, L, lam + i, co, rhs + i, cl); break;
+    case 2: cut_row_one<2>(s5, vars, nv, L, lam + i, co, rhs + i, cl, eig ? eig + c : nullptr); break;
+    case 3: cut_row_one<3>(s5, vars, nv, L, lam + i, co, rhs + i, cl, eig ? eig + c : nullptr); break;
+    case 4: cut_row_one<4>(s5, vars, nv, L, lam + i, co, rhs + i, cl, eig ? eig + c : nullptr); break;
+    default: cut_row_one<5>(s5, vars, nv, L, lam + i, co, rhs + i, cl, eig ? eig + c : nullptr); break;
     }
 #pragma unroll
     for (int m = 0; m < SDPCUT_ROW_LD; ++m) {
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
                                                         const int32_t *set5, const int32_t *ks, const double *vars,
                                                         int32_t nv, int64_t L, int coef_ld, char *block,
                                                         int64_t hdr_bytes, uint64_t *zero_ptr, int zero_words,
-                                                        int64_t done_serial, uint32_t *done_ticket)
+                                                        int64_t done_serial, uint32_t *done_ticket, const double *eig)
 {
     __shared__ double tile[64 * SDPCUT_ROW_LD];
     const int lane = threadIdx.x;
@@ -173,10 +190,10 @@ __global__ __launch_bounds__(64) void round_rows_kernel(int64_t cap, const int64
             k = ks[c];
             const int32_t *s5 = set5 + c * 5;
             switch (k) {
-            case 2: cut_row_one<2>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            case 3: cut_row_one<3>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            case 4: cut_row_one<4>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
-            default: cut_row_one<5>(s5, vars, nv, L, &lam, co, &rhs, cl); break;
+            case 2: cut_row_one<2>(s5, vars, nv, L, &lam, co, &rhs, cl, eig ? eig + c : nullptr); break;
+            case 3: cut_row_one<3>(s5, vars, nv, L, &lam, co, &rhs, cl, eig ? eig + c : nullptr); break;
+            case 4: cut_row_one<4>(s5, vars, nv, L, &lam, co, &rhs, cl, eig ? eig + c : nullptr); break;
+            default: cut_row_one<5>(s5, vars, nv, L, &lam, co, &rhs, cl, eig ? eig + c : nullptr); break;
             }
         }
         o_lam[i] = lam;
@@ -231,6 +248,7 @@ struct RoundCsrArgs {
     const double *vars;
     int32_t nv;
     int64_t L;
+    const double *eig;         // [N] lambda_min of every candidate at this point if the scoring pass computed it, else NULL
     // outputs: device view of the pinned host block
     int64_t *o_hdr;            // [16]: 0..6 selection counters, 7 completion serial, 8 cuts, 9 non-zeros, 10 look-back gave up
                                // (the host zeroes word 10 before the launch)
@@ -286,10 +304,10 @@ __global__ __launch_bounds__(64) void round_csr_kernel(RoundCsrArgs R)
 #pragma unroll
             for (int a = 0; a < 5; ++a) s5[a] = sp[a];
             switch (k) {
-            case 2: cut_row_one<2>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl); break;
-            case 3: cut_row_one<3>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl); break;
-            case 4: cut_row_one<4>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl); break;
-            default: cut_row_one<5>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl); break;
+            case 2: cut_row_one<2>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl, R.eig ? R.eig + c : nullptr); break;
+            case 3: cut_row_one<3>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl, R.eig ? R.eig + c : nullptr); break;
+            case 4: cut_row_one<4>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl, R.eig ? R.eig + c : nullptr); break;
+            default: cut_row_one<5>(sp, R.vars, R.nv, R.L, &lam, co, &rhs, cl, R.eig ? R.eig + c : nullptr); break;
             }
         }
         R.o_lam[i] = lam;
@@ -382,7 +400,7 @@ int launch_cut_rows(sdpcut_ctx *h, int64_t count, const int64_t *d_limit, const 
     const int grid = (int)((count + 63) / 64);
     hipLaunchKernelGGL(cut_rows_kernel, dim3(grid), dim3(64), 0, h->stream, count, d_limit, d_idx, idx_base,
                        h->N, h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, d_lam, d_coef, coef_ld, d_rhs, d_cols,
-                       d_ks);
+                       d_ks, (h->scored & SDPCUT_EIG) ? (const double *)h->d_eig : (const double *)nullptr);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -411,7 +429,7 @@ int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int
     const int grid = (int)((cap + 63) / 64);
     hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
                        h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw, done_serial,
-                       h->d_done_ticket);
+                       h->d_done_ticket, (h->scored & SDPCUT_EIG) ? (const double *)h->d_eig : (const double *)nullptr);
     HIP_TRY(h, hipGetLastError());
     h->topk_alt_clean = true;
     return 0;
@@ -454,6 +472,7 @@ int launch_round_csr(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, int64_t li
     RoundCsrArgs R;
     R.cap = cap; R.d_c4 = d_c4; R.limit = limit; R.idx = d_idx; R.score = d_score; R.idx_base = h->base; R.n_local = h->N;
     R.set5 = h->d_set_orig; R.ks = h->d_k; R.vars = h->d_vars; R.nv = h->nb_vars; R.L = h->L;
+    R.eig = (h->scored & SDPCUT_EIG) ? h->d_eig : nullptr;
     const CsrLayout y = csr_layout(cap, ld);
     char *b = (char *)block;
     R.o_hdr = (int64_t *)b;

@@ -358,7 +358,13 @@ def test_handle_rebound_to_a_larger_instance_after_a_fused_round(pkg, oracle):
                 assert np.array_equal(r["idx"], order[:w]), (nb_vars, strat)
                 assert np.array_equal(r["score"], ref_score[:w] + 0.0) and r["new_strat"] == ref_strat
                 lam, coef, rhs, cols, ks = sc.cut_rows(order[:w])
-                assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], coef[:, :r["coef"].shape[1]])
+                # (bit-equal when both sides had lambda_min at hand or both had not; after an optimality round the fused rows
+                # come from Jacobi, the explicit ones -- the eigenvalues now being scored -- from inverse iteration)
+                cw = coef[:, :r["coef"].shape[1]]
+                if strat == 2:
+                    assert np.abs(r["lam"] - lam).max() <= 2e-13 and np.abs(r["coef"] - cw).max() <= 1e-9
+                else:
+                    assert np.array_equal(r["lam"], lam) and np.array_equal(r["coef"], cw)
         assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
     finally:
         sc.close()

@@ -257,7 +257,9 @@ def test_dropin_pair_hands_over_the_fused_rows(pkg, strat):
     nb_d = d._gen_eigcuts_selected(strat, 5000, rl_old, vars_values=vv)
     dd, cd, ld_ = d._my_prob.linear_constraints.csr_parts()
     da, ca, la = st_a.csr_parts()
-    assert nb_d == nb_a and np.array_equal(dd, da) and np.array_equal(cd, ca)
+    # (the stale list's rows are generated after a fresh upload of the point, by Jacobi when the round's eigenvalues are gone:
+    # the same cuts to the accuracy two eigen-solvers agree to)
+    assert nb_d == nb_a and np.array_equal(cd, ca) and np.abs(dd - da).max() <= 1e-9
 
 
 def test_qcqp_round_keeps_the_fused_rows_through_slices(pkg, oracle, golden_qcqp):
@@ -565,3 +567,64 @@ def test_small_size_classes_on_side_streams_give_the_same_round(pkg):
     finally:
         a.close()
         b.close()
+
+
+# ----------------------------------------------------------------------------- eigenvector of a known lambda_min
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_rows_by_inverse_iteration_agree_with_jacobi(pkg, k):
+    """When the scoring pass has computed lambda_min, the cut rows take its eigenvector by inverse iteration (jacobi.h,
+    min_eigvec_known) instead of a second Jacobi with vectors.  Against the Jacobi rows of the same candidates: lambda to
+    2e-13; coefficients to 1e-9 wherever LAPACK says the smallest eigenvalue is separated by 1e-6 (two eigen-solvers agree to
+    eps / gap, no better); for EVERY row the two properties that make it the eigen-cut of lambda_min whatever the solver --
+    unit vector, Rayleigh quotient = lambda_min; and at a structured vertex (x = 0.5, X in {0, 0.5}), where lambda_min is
+    multiple for many candidates, those candidates are left to Jacobi: bit-equal rows."""
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    n, count = 40, 60000
+    L = n * (n + 1) // 2
+    Q_arr, vv, rng = synthetic.make_instance(n, 5 + k)
+    S = np.full((count, 5), -1, dtype=np.int32)
+    S[:, :k] = synthetic.random_index_sets(n, k, count, rng)
+    ks = np.full(count, k, dtype=np.int32)
+    X = np.triu(rng.integers(0, 2, (n, n)), 1) * 0.5
+    X = X + X.T + 0.5 * np.eye(n)
+    vertex = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(n, Q_arr)
+        sc.set_candidates(S, ks)
+        ids = np.arange(count, dtype=np.int64)
+        for point, structured in ((vv, False), (vertex, True)):
+            sc.set_point(point)
+            sc.score(_capi.NN)
+            lam_j, coef_j, rhs_j, cols, _ = sc.cut_rows(ids)              # no eigenvalues at hand: Jacobi with vectors
+            sc.score(_capi.EIG)
+            lam_i, coef_i, rhs_i, cols_i, _ = sc.cut_rows(ids)            # lambda_min known: inverse iteration
+            assert np.array_equal(cols, cols_i) and np.abs(lam_i - lam_j).max() <= 2e-13
+            x, Xp = point[L:], point[:L]
+            si = S[:, :k].astype(np.int64)
+            M = np.zeros((count, k + 1, k + 1))
+            M[:, 0, 0] = 1.0
+            M[:, 0, 1:] = M[:, 1:, 0] = x[si]
+            for a in range(k):
+                for b in range(a, k):
+                    M[:, 1 + a, 1 + b] = M[:, 1 + b, 1 + a] = Xp[n * si[:, a] - si[:, a] * (si[:, a] + 1) // 2 + si[:, b]]
+            w = np.linalg.eigvalsh(M)
+            gap = w[:, 1] - w[:, 0]
+            m = k + k * (k + 1) // 2
+            sep = gap >= 1e-6
+            assert sep.sum() > (0 if structured else count // 2)
+            assert np.abs(coef_i[sep, :m] - coef_j[sep, :m]).max() <= 1e-9 and np.abs(rhs_i[sep] - rhs_j[sep]).max() <= 1e-9
+            # the cut of a unit vector v is  sum coef * value - rhs = v' M v  (cut_select_qp.py:745-750); v0^2 = -rhs
+            vals = point[cols[:, :m].astype(np.int64)]
+            for lam, coef, rhs in ((lam_i, coef_i, rhs_i), (lam_j, coef_j, rhs_j)):
+                rq = (coef[:, :m] * vals).sum(axis=1) - rhs
+                assert np.abs(rq - lam).max() <= 1e-11, np.abs(rq - lam).max()
+                diag = [k + sum(k - t for t in range(a)) for a in range(k)]          # positions of the X_aa coefficients = v_a^2
+                assert np.abs(coef[:, diag].sum(axis=1) - rhs - 1.0).max() <= 1e-12
+            if structured:
+                multiple = gap <= 1e-12
+                assert multiple.sum() > (100 if k >= 4 else -1), (k, int(multiple.sum()))
+                assert np.array_equal(coef_i[multiple], coef_j[multiple]) and np.array_equal(rhs_i[multiple], rhs_j[multiple])
+    finally:
+        sc.close()
