@@ -331,7 +331,7 @@ __device__ __forceinline__ void fill_lifted(double (&a)[K + 1][K + 1], const dou
 // whatever the multiplicity of lam (for a multiple lambda_min it is SOME unit vector of the eigenspace, as LAPACK's and
 // Jacobi's are); its distance from LAPACK's eigenvector is eps / gap like any method's.  Row exchanges are selects over
 // compile-time indices (no scratch).  Returns the residual max |A v - lam v| / ||A|| -- or 1 if lam is a multiple eigenvalue (see
-// the end); the caller falls back to Jacobi if it is not tiny (for simple eigenvalues never observed: tests/test_gpu_round3.py, oracle prototype over 30 000 matrices incl. rank-one and vertex ones).
+// the end); the caller falls back to Jacobi if it is not tiny (for simple eigenvalues never observed: tests/test_gpu_round3.py, and a numpy prototype of these steps over 30 000 matrices incl. rank-one and vertex ones).
 template <int D>
 __device__ __forceinline__ double min_eigvec_known(const double (&a)[D][D], double lam, double (&v)[D])
 {
