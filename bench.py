@@ -323,6 +323,34 @@ def bench_mixed_cover(device_index, steps):
     return out
 
 
+def bench_triangle(device_index, steps):
+    """ms per triangle-inequality separation step (cut_select_qp.py:824-863: all 4 T inequalities of spar125-075-1 evaluated and
+    ranked by (density, violation) on the device, the selected ones handed to the LP's row store as one CSR block) at the LP
+    point the reference's trajectory recorded for round 3."""
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolver
+    gold = os.path.join(ROOT, "tests", "golden")
+    g = np.load(os.path.join(gold, "rounds_spar125_075_1_d4_s4.npz"))
+    inst = harness.parse_boxqp(os.path.join(gold, "instances", C3_INSTANCE + ".in"))
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    cs = CutSolver(device_index)
+    cs._dim, cs._nb_vars, cs._nb_lifted, cs._Q_arr, cs._Q_adj = 4, n, L, inst["Q_arr"], inst["adj"]
+    cs._my_prob = harness.LinearRelaxation(np.zeros(L + n))
+    cs._preprocess_triangle_ineq()
+    vv = g["r03_vars"]
+    for _ in range(5):
+        cs._my_prob.linear_constraints = harness._RowStore()
+        nb = cs._separate_and_add_triangle(0.1, vv)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cs._my_prob.linear_constraints = harness._RowStore()
+        nb = cs._separate_and_add_triangle(0.1, vv)
+    dt = (time.perf_counter() - t0) / steps
+    cs._gpu_tri.close()
+    return {"instance": C3_INSTANCE, "triples": int(len(cs._gpu_tri_triples)), "inequalities": 4 * int(len(cs._gpu_tri_triples)),
+            "cuts": int(nb), "step_ms": dt * 1e3, "steps": steps}
+
+
 def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     """the feasibility round (strategy 1) on the main workload: eigenvalue-only kernel + selection + rows"""
     import torch
@@ -671,6 +699,7 @@ def main():
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))
                 out["secondary"]["mixed_cover"] = bench_mixed_cover(local_rank, max(50, args.steps // 2))
+                out["secondary"]["triangle"] = bench_triangle(local_rank, max(20, args.steps // 4))
         if world == 1 and not args.no_cpu_baseline:
             vv_host = np.array(vv_host)     # (detach from the handle's pinned buffer: worker processes pickle it)
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample
