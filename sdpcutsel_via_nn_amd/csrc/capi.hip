@@ -260,7 +260,8 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         int least = 0, greatest = 0;
         HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
         hipStream_t s = nullptr;
-        HIP_TRY(h, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, value != 0 ? greatest : least));
+        // (0 = the priority hipStreamCreateWithFlags gives: normal, which lies between the two ends of the range)
+        HIP_TRY(h, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, value != 0 ? greatest : (0 < greatest ? greatest : (0 > least ? least : 0))));
         const bool on_own = h->stream == h->own_stream;
         if (h->own_stream) {
             HIP_TRY(h, hipStreamSynchronize(h->own_stream));
