@@ -611,6 +611,9 @@ class GpuCutSelectionMixin(object):
             if pend is None:
                 b.begin(strat, head, vv, flags)
             if spec:
+                if f[0].n_at_bind < b.n_at_bind and not f[0].prioritised:      # (the other way round: the follower is the short list)
+                    f[0].scorer.set_option(_capi.OPT_STREAM_PRIORITY, 1)
+                    f[0].prioritised = True
                 f[0].begin(1, f[1], vv, _capi.EIG)
             fused = b.end()
             idx, score = fused["idx"].copy(), fused["score"].copy()
