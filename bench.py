@@ -308,7 +308,9 @@ def bench_mixed_cover(device_index, steps):
         rec = {"candidates": N, "sizes_2_to_5": np.bincount(ks, minlength=6)[2:].tolist(), "sel_size": sel, "steps": steps}
         for r in (2, 9):
             vv, strat = np.ascontiguousarray(g["r%02d_vars" % r]), int(g["r%02d_strat" % r])
-            for side in (2, 0):      # 2: the library's default (measured once per list), 0: one launch after the other
+            for one, side in ((1, 2), (0, 2), (0, 0)):      # the default: ONE launch over all size classes; a launch per class with the
+                # small ones on side streams if that measures faster in this process; one launch after the other
+                sc.set_option(_capi.OPT_ONE_LAUNCH, one)
                 sc.set_option(_capi.OPT_SIDE_STREAMS, side)
                 for _ in range(30):
                     sc.round_csr(strat, sel, point=vv)
@@ -317,7 +319,8 @@ def bench_mixed_cover(device_index, steps):
                 for _ in range(steps):
                     res = sc.round_csr(strat, sel, point=vv)
                 us = (time.perf_counter() - t0) / steps * 1e6
-                rec["round_%d_strategy_%d%s" % (r, strat, "" if side else "_classes_one_after_the_other")] = {"round_us": us, "cuts": int(res["rhs"].shape[0])}
+                form = "" if one else ("_launch_per_class_side_streams_if_faster" if side else "_launch_per_class_one_after_the_other")
+                rec["round_%d_strategy_%d%s" % (r, strat, form)] = {"round_us": us, "cuts": int(res["rhs"].shape[0])}
         sc.close()
         out[name + "_dim%d" % dim] = rec
     return out

@@ -80,6 +80,9 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
 /* SDPCUT_OPT_EIG_KERNEL (default 1): launches that compute only lambda_min (feasibility rounds,
  * cut_select_qp.py:639-654) run the dedicated eigenvalue kernel -- one launch over all size classes, compiled
  * without the MLP's register state -- instead of the scoring kernels' eigenvalue branch (0: A/B). */
+/* SDPCUT_OPT_ONE_LAUNCH (default 1): a list with several size classes is scored by ONE launch in which every class has its own
+ * range of workgroups (the shipped networks; same scores bit for bit as a launch per class).  0, or a list the launch does not
+ * cover (user networks that need the clamped path, the VALU / simple kernel variants): a launch per class, see the next option. */
 /* SDPCUT_OPT_SIDE_STREAMS (default 2): a list with several size classes may score its smaller classes on side streams of the handle,
  * between a fork and a join event, next to the largest class on the handle's stream.  0: one launch after the other; 1: side
  * streams; 2: the first multi-class scoring of a candidate list measures both forms (~1 ms, once) and keeps the faster --
@@ -90,7 +93,7 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * behind them.  Not allowed while a round is pending; ignored by a handle that runs on a caller's stream (sdpcut_set_stream). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
        SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6, SDPCUT_OPT_EIG_KERNEL = 7, SDPCUT_OPT_STREAM_PRIORITY = 8,
-       SDPCUT_OPT_SIDE_STREAMS = 9 };
+       SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10 };
 
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier

@@ -248,6 +248,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_TIMING:
         h->timing = value <= 0 ? 0 : (value == 1 ? 1 : 2);
         return SDPCUT_OK;
+    case SDPCUT_OPT_ONE_LAUNCH:
+        h->one_launch = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_SIDE_STREAMS:
         if (value < 0 || value > 2) return sdpcut_fail(h, SDPCUT_EINVAL, "SDPCUT_OPT_SIDE_STREAMS: 0 off, 1 on, 2 measured");
         h->side_streams = (int)value;

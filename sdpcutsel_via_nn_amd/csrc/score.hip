@@ -441,8 +441,26 @@ __device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], c
 #endif
 constexpr int mfma_cols(int K) { return K == 2 ? SDPCUT_MFMA_J_K2 : K == 3 ? SDPCUT_MFMA_J_K3 : K == 4 ? SDPCUT_MFMA_J_K4 : SDPCUT_MFMA_J_K5; }
 
-template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true, int JK = 2>
-__global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void score_mfma_kernel(ScoreArgs A)
+// LDS of one workgroup of the MFMA kernel for size class K (a union of these serves the launch over all classes)
+template <int K, int H, int NH>
+struct MfmaLds {
+    static constexpr int S0 = (K + K * (K + 1) / 2 + 3) / 4;
+    static constexpr int T = (H + 15) / 16;
+    static constexpr int NT = (H - 16 * (T - 1) <= 4) ? H - 16 * (T - 1) : 0;
+    double feat[4][S0 * 4][64];  // per wave: feature-major strip of 64 candidates
+    double ynn[4][64];           // per wave: raw network outputs
+    double s_bias[NH * 64];
+    double s_wtail[NT ? NH * 4 * 64 : 1];
+    double s_wout[64];
+    uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
+    uint32_t tk_cnt[2];
+    uint32_t s_strong;
+};
+
+// bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
+// one class; the launch over all classes of a list hands every class its own range of workgroups, score_mfma_all_kernel)
+template <int K, int H, int NH, int FUSE, bool CLAMP, int JK>
+__device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H, NH> &S, const int bid, const int nblk)
 {
     constexpr int M = K * (K + 1) / 2;
     constexpr int DIN = K + M;
@@ -456,8 +474,8 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     static_assert(JK == 1 || JK == 2, "one or two column tiles per pass");
     static_assert(T == 4, "hidden width must be in 49..64");
 
-    __shared__ double feat[4][S0 * 4][64];  // per wave: feature-major strip of 64 candidates
-    __shared__ double ynn[4][64];           // per wave: raw network outputs
+    auto &feat = S.feat;
+    auto &ynn = S.ynn;
 
     const int lane = threadIdx.x & 63;
     // (wave-uniform by construction; said so to the compiler: the wave's range, its strip loop and pass counts are then scalar)
@@ -476,8 +494,8 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     //    not pay: a single-tile pass of a lone wave takes as long as a two-tile pass, profiles/r03_k3_kernel_time_vs_list_length.txt.)
     // The last strip of a list may hold fewer candidates: it runs the passes its column tiles need, the last one over a single
     // tile if their number is odd (mlp_pass<1>: the same arithmetic per candidate, bit-equal scores).
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t wstride = (int64_t)gridDim.x * 4 * A.strip;      // candidates between two strips of one wave
+    const int64_t gw = (int64_t)bid * 4 + wave;
+    const int64_t wstride = (int64_t)nblk * 4 * A.strip;      // candidates between two strips of one wave
     const int64_t c_first = gw * A.strip;
 
     // The index set (and the output slot) of the NEXT strip are requested before phase B of the
@@ -495,9 +513,9 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     }
 
 #if SDPCUT_SMALL_IN_LDS
-    __shared__ double s_bias[NH * 64];
-    __shared__ double s_wtail[NT ? NH * 4 * 64 : 1];
-    __shared__ double s_wout[64];
+    auto &s_bias = S.s_bias;
+    auto &s_wtail = S.s_wtail;
+    auto &s_wout = S.s_wout;
     if (A.flags & SDPCUT_NN) {     // uniform; an eigenvalue-only launch may come without a network
         for (int i = threadIdx.x; i < NH * 64; i += 256) s_bias[i] = net.bias_q[i];
         if constexpr (NT > 0)
@@ -508,8 +526,8 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
 #endif
 
     // leading-digit histograms of the selection that follows (A.tk != nullptr)
-    __shared__ uint32_t tk_hist[256];
-    __shared__ uint32_t tk_cnt[2];
+    auto &tk_hist = S.tk_hist;
+    auto &tk_cnt = S.tk_cnt;
     uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
     if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
@@ -778,7 +796,7 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
     }
     PHASE_REPORT;
     if (A.strong_out) {      // uniform: one no-return atomic per workgroup, into one of eight replicas
-        __shared__ uint32_t s_strong;
+        uint32_t &s_strong = S.s_strong;
         if (threadIdx.x == 0) s_strong = 0;
         __syncthreads();
         for (int off = 32; off > 0; off >>= 1) c_strong += __shfl_xor((int)c_strong, off);
@@ -808,6 +826,47 @@ __global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void sco
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int K, int H, int NH, int FUSE = 0, bool CLAMP = true, int JK = 2>
+__global__ __launch_bounds__(256, (JK == 1 ? SDPCUT_MFMA_J1_WAVES : 2)) void score_mfma_kernel(ScoreArgs A)
+{
+    __shared__ MfmaLds<K, H, NH> S;
+    score_mfma_body<K, H, NH, FUSE, CLAMP, JK>(A, S, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ONE launch for every size class of a list (r3).  Real covers hold one large class and a few sets of the smaller sizes
+// (spar100-050-1, dim 5: 72 673 five-variable sets, 103 of four, 1 of three); a launch per class costs what one pass costs however
+// few candidates it holds, and side streams run side by side only if the process's streams were handed different hardware queues.
+// Here every class gets its own range of workgroups of one launch, the largest class first; a workgroup serves exactly one
+// class (its code is the single-class kernel's, its LDS a union of the classes').
+struct ScoreArgsAll {
+    ScoreArgs a[SDPCUT_MAX_K - 1];      // classes in launch order
+    int32_t k[SDPCUT_MAX_K - 1];        // their sizes
+    int32_t bend[SDPCUT_MAX_K - 1];     // one past their last workgroup
+    int32_t nclasses;
+};
+
+template <int FUSE, bool CLAMP>
+__global__ __launch_bounds__(256, 2) void score_mfma_all_kernel(ScoreArgsAll AA)
+{
+    __shared__ union LdsAll {
+        MfmaLds<2, 64, 3> l2;
+        MfmaLds<3, 50, 3> l3;
+        MfmaLds<4, 50, 3> l4;
+        MfmaLds<5, 64, 4> l5;
+        __device__ LdsAll() {}
+    } S;
+    int c = 0;
+    while (c + 1 < AA.nclasses && (int)blockIdx.x >= AA.bend[c]) ++c;      // uniform
+    const int b0 = c ? AA.bend[c - 1] : 0;
+    const int bid = (int)blockIdx.x - b0, nblk = AA.bend[c] - b0;
+    switch (AA.k[c]) {
+    case 2: score_mfma_body<2, 64, 3, FUSE, CLAMP, 2>(AA.a[c], S.l2, bid, nblk); break;
+    case 3: score_mfma_body<3, 50, 3, FUSE, CLAMP, 2>(AA.a[c], S.l3, bid, nblk); break;
+    case 4: score_mfma_body<4, 50, 3, FUSE, CLAMP, 2>(AA.a[c], S.l4, bid, nblk); break;
+    default: score_mfma_body<5, 64, 4, FUSE, CLAMP, 2>(AA.a[c], S.l5, bid, nblk); break;
     }
 }
 
@@ -1199,6 +1258,61 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     return 0;
 }
 
+// One launch over all size classes of the list (score_mfma_all_kernel): possible when every class runs the MFMA kernels with
+// the shipped kind of network (pre-activations provably bounded: the clamp-free instantiation, whose scores are what the
+// per-class launches of such networks produce, bit for bit) and, with a fused selection, one of its histogram modes.
+// -> 1 launched, 0 not applicable (the caller launches per class), < 0 error.
+static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, int64_t *strong_out, hipEvent_t ev_start,
+                              hipEvent_t ev_stop)
+{
+    if (h->kernel_variant != SDPCUT_KERNEL_MFMA || !(flags & SDPCUT_NN)) return 0;
+    const int f = fuse ? fuse->mode : 0;
+    if (f != 0 && f != TK_MODE_FEAS && f != TK_MODE_OPT && f != TK_MODE_STRONG) return 0;
+    if (f == TK_MODE_FEAS && !(flags & SDPCUT_EIG)) return 0;
+    ScoreArgsAll AA;
+    AA.nclasses = 0;
+    int order[SDPCUT_MAX_K - 1], m = 0;
+    for (int k = 2; k <= SDPCUT_MAX_K; ++k)
+        if (h->bucket[k].n > 0) {
+            if (!h->net[k].set || !net_shape_ok(h, k, flags) || !h->net[k].dev.unclamped_ok) return 0;
+            order[m++] = k;
+        }
+    for (int i = 1; i < m; ++i)      // the largest class first: its workgroups are the launch's critical path
+        for (int j = i; j > 0 && h->bucket[order[j]].n > h->bucket[order[j - 1]].n; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int64_t blocks = 0;
+    for (int i = 0; i < m; ++i) {
+        const int k = order[i];
+        const Bucket &b = h->bucket[k];
+        ScoreArgs &A = AA.a[i];
+        A.set = b.d_set; A.orig = b.d_orig; A.n = b.n;
+        A.strip = 64;
+        A.vars = h->d_vars; A.Q = h->d_Q; A.nv = h->nb_vars; A.L = h->L;
+        A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
+        A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
+        A.tk_mode = f;
+        A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
+        A.net = h->net[k].dev;
+        int grid = grid_for(h, (b.n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
+        if (b.n <= 32 * (int64_t)h->n_cu * 4 * 2) {      // (the same split as a launch over this class alone: launch_score_k)
+            A.strip = 32;
+            grid = (int)(((b.n + 31) / 32 + 3) / 4);
+        }
+        blocks += grid;
+        AA.k[i] = k;
+        AA.bend[i] = (int32_t)blocks;
+    }
+    AA.nclasses = m;
+    hipStream_t st = h->stream;
+    const int grid = (int)blocks;
+    ScoreArgsAll &A = AA;
+    if (f == TK_MODE_STRONG) SCORE_LAUNCH((score_mfma_all_kernel<TK_MODE_STRONG, false>), grid, 256);
+    else if (f == TK_MODE_OPT) SCORE_LAUNCH((score_mfma_all_kernel<TK_MODE_OPT, false>), grid, 256);
+    else if (f == TK_MODE_FEAS) SCORE_LAUNCH((score_mfma_all_kernel<TK_MODE_FEAS, false>), grid, 256);
+    else SCORE_LAUNCH((score_mfma_all_kernel<0, false>), grid, 256);
+    HIP_TRY(h, hipGetLastError());
+    return 1;
+}
+
 static int ensure_side_streams(sdpcut_ctx *h)
 {
     if (h->ev_fork) return 0;
@@ -1323,6 +1437,10 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
         }
     h->timed_score = h->timing && first;
     int rc;
+    if (nclasses > 1 && h->one_launch) {
+        rc = launch_classes_one(h, flags, fuse, strong_out, h->timed_score ? h->ev[0] : nullptr, h->timed_score ? h->ev[1] : nullptr);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     if (nclasses > 1 && !h->timed_score && h->side_streams) {
         if (h->side_streams == 2 && h->side_choice < 0 && (rc = calibrate_side_streams(h, flags, kbig))) return rc;
         if (h->side_streams == 1 || h->side_choice == 1) return launch_classes_side(h, flags, fuse, strong_out, kbig);

@@ -530,9 +530,10 @@ def test_qcqp_loop_begins_both_covers_rounds_together(pkg, oracle, golden_qcqp, 
 
 
 def test_small_size_classes_on_side_streams_give_the_same_round(pkg):
-    """SDPCUT_OPT_SIDE_STREAMS: a list with one large and several small size classes scored with the small classes on side streams
-    (1), one launch after the other (0) and with the form measured at first use (2, the default): the same round bit for bit,
-    also right after a new list and next to a second handle's round."""
+    """A list with one large and several small size classes scored by ONE launch over all classes (SDPCUT_OPT_ONE_LAUNCH, the
+    default), by a launch per class one after the other, with the small classes on side streams, and with that form measured at
+    first use (SDPCUT_OPT_SIDE_STREAMS 0 / 1 / 2): the same scores and the same round bit for bit, also right after a new list and
+    next to a second handle's round."""
     from sdpcutsel_via_nn_amd import _capi
     Q_arr, vv, S, ks = _mixed_workload(60, (5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 3, 2), 33000, seed=41)
     a, b = pkg.Scorer(0), pkg.Scorer(0)
@@ -544,14 +545,22 @@ def test_small_size_classes_on_side_streams_give_the_same_round(pkg):
         b.set_candidates(S[:5000], ks[:5000])
         fields = ("idx", "score", "lam", "row_entry", "indptr", "indices", "values", "rhs")
         ref = {}
-        for mode in (0, 1, 2, 2):
+        for one, mode in ((0, 0), (0, 1), (0, 2), (0, 2), (1, 2)):      # a launch per class (sequential / side streams / measured); ONE launch
+            a.set_option(_capi.OPT_ONE_LAUNCH, one)
             a.set_option(_capi.OPT_SIDE_STREAMS, mode)
             for strat in (4, 2, 1):
                 r = a.round_csr(strat, 3000, point=vv, copy=True)
-                if mode == 0:
+                if (one, mode) == (0, 0):
                     ref[strat] = r
                 else:
-                    assert all(np.array_equal(r[f], ref[strat][f]) for f in fields) and r["counters"] == ref[strat]["counters"], (mode, strat)
+                    assert all(np.array_equal(r[f], ref[strat][f]) for f in fields) and r["counters"] == ref[strat]["counters"], (one, mode, strat)
+            a.score(_capi.EIG | _capi.NN)
+            e, o = a.get_scores()
+            if (one, mode) == (0, 0):
+                ref["scores"] = (e, o)
+            else:
+                assert np.array_equal(e, ref["scores"][0]) and np.array_equal(o, ref["scores"][1]), (one, mode)
+        a.set_option(_capi.OPT_ONE_LAUNCH, 0)
         a.set_candidates(S[::-1].copy(), ks[::-1].copy())          # a new list measures again
         r0 = a.round_csr(4, 3000, point=vv, copy=True)
         a.set_option(_capi.OPT_SIDE_STREAMS, 0)

@@ -27,7 +27,8 @@ p = "r%02d_" % r
 vv, strat = np.ascontiguousarray(g[p + "vars"]), int(g[p + "strat"])
 from sdpcutsel_via_nn_amd import _capi  # noqa: E402
 out = []
-for side in (2, 0):      # the library's default (measured once per list) / one launch after the other
+for side in (2, 0):      # the library's default (one launch over all size classes) / a launch per class, one after the other
+    sc.set_option(_capi.OPT_ONE_LAUNCH, 1 if side else 0)
     sc.set_option(_capi.OPT_SIDE_STREAMS, side)
     for _ in range(50):
         sc.round_csr(strat, sel, point=vv)
