@@ -16,7 +16,7 @@ def show(lo, hi, title):
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         print("%9.1f us  dur %7.1f  end %7.1f  queue %-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, (e - t0) / 1e3, r.get('Queue_Id', '?'), r['Kernel_Name'][:64]))
 h = len(per) // 2
-show(per[h - 3], per[h - 1], "--- two rounds, small size classes on side streams")
-show(per[-3], per[-1], "--- two rounds, one launch after the other")
+show(per[h - 3], per[h - 1], "--- two rounds, ONE launch over all size classes (default)")
+show(per[-3], per[-1], "--- two rounds, a launch per class one after the other")
 PY
 cat gpurun_out/$3.txt
