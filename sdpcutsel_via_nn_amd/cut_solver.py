@@ -133,6 +133,20 @@ class RankList(Sequence):
         self._need(count)
         return self._score[:count]
 
+    def count_above(self, thr):
+        """Number of entries of the WHOLE list whose score exceeds ``thr`` (cut_select_qcqp.py:85-87 counts the entries above
+        BIG_M).  The list is sorted by score, so the head answers when its last score is <= thr; under the combined strategy a
+        head that consists of marked entries only (obj_improve + BIG_M, cut_select_qp.py:611) answers too when the entries behind
+        it -- the ones the scan never reached, all with an obj_improve no larger than the last marked one's -- cannot exceed thr.
+        Otherwise the complete ranking is fetched."""
+        h = self._score
+        if self._have == 0:
+            return 0
+        last = float(h[self._have - 1])
+        if self._have >= self._n or last <= thr or (self._strat == 4 and last > _BIG_M and last - _BIG_M <= thr):
+            return int(np.count_nonzero(h[:self._have] > thr))
+        return int(np.count_nonzero(self.scores() > thr))
+
     def _sets(self, lo, hi, loc):
         """(index sets [m, 5], sizes [m]) of positions [lo, hi): from the fused round's head when it covers them"""
         if self._head_sets is not None and hi <= self._head_sets.shape[0]:
@@ -989,7 +1003,8 @@ class CutSolverQCQP(CutSolver):
             nb = self._gen_eigcuts_selected(strat_old, sel_size, rank_list, vars_values=vars_values)
             return strat, rank_list, nb, 0
         # :85-92 counters, from the device arrays instead of a Python loop over N tuples
-        nb_opt_cuts = int(np.count_nonzero(comb_obj.scores() > _BIG_M)) if len(comb_obj) else 0
+        nb_opt_cuts = (comb_obj.count_above(_BIG_M) if isinstance(comb_obj, RankList) else
+                       int(np.count_nonzero(np.array([e[1] for e in comb_obj]) > _BIG_M))) if len(comb_obj) else 0
         nb_cuts_combined = n_obj      # :90-92 counts the entries whose first field is an int: the objective cover's (optimality / combined entries)
         rest = sel_size - nb_cuts_combined
         nb_a = self._gen_eigcuts_selected(1, rest, feas_cons[0:rest], vars_values=vars_values)

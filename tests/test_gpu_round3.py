@@ -637,3 +637,30 @@ def test_rows_by_inverse_iteration_agree_with_jacobi(pkg, k):
                 assert np.array_equal(coef_i[multiple], coef_j[multiple]) and np.array_equal(rhs_i[multiple], rhs_j[multiple])
     finally:
         sc.close()
+
+
+def test_count_above_answers_from_the_head_what_the_whole_list_says(pkg):
+    """RankList.count_above (the nb_opt_cuts counter of cut_select_qcqp.py:85-87) from the head of the list == the count over
+    the completely ranked list: combined strategy in both regimes, optimality, feasibility, thresholds inside and outside the head."""
+    from sdpcutsel_via_nn_amd import harness
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolver, AggArrays, RankList, _BIG_M
+    Q_arr, vv, S, ks = _mixed_workload(40, (2, 3, 4), 30000, seed=9)
+    n, L = 40, 820
+    x = vv[L:]
+    iu = np.triu_indices(n)
+    psd = np.concatenate([np.minimum(x[iu[0]], x[iu[1]]), x])
+    for point in (vv, 0.999 * psd + 0.001 * vv):
+        for strat, sel in ((4, 300), (4, 5000), (2, 0), (1, 0)):
+            cs = CutSolver()
+            cs.set_instance(n, Q_arr, AggArrays(S, ks, n, Q_arr), 4, my_prob=harness.LinearRelaxation(np.zeros(L + n)))
+            out = cs._sel_eigcut_by_ordering_on_measure(strat, point, 1, **({"sel_size": sel} if strat == 4 else {}))
+            rl = out[1] if strat == 4 else out
+            if not isinstance(rl, RankList):
+                continue                                  # (an empty feasibility list)
+            head_scores = np.array(rl._score[:rl._have])
+            thresholds = [_BIG_M, 0.0, -_BIG_M, 2 * _BIG_M]
+            if head_scores.size:
+                thresholds += [float(np.median(head_scores)), float(head_scores.min()), float(head_scores.min()) - 1e-3]
+            quick = [rl.count_above(t) for t in thresholds]
+            full = rl.scores()                            # the complete ranking
+            assert quick == [int(np.count_nonzero(full > t)) for t in thresholds], (strat, sel, quick)
