@@ -156,3 +156,109 @@ def test_round_csr_struct_matches_the_header():
                 os.remove(p)
     assert out[0] == ctypes.sizeof(_capi.RoundCsr)
     assert out[1:] == [getattr(_capi.RoundCsr, n).offset for n in fields]
+
+
+# ----------------------------------------------------------------------------- the QCQP pairing, without a device
+class _RecordingScorer(object):
+    """stands in for _capi.Scorer: records the calls of the two-halves API and answers with a canned round"""
+    log = []
+    base = 0
+
+    def __init__(self, name, n):
+        self.name, self.n, self.round_count, self.pending = name, n, 0, None
+
+    def set_option(self, opt, value):
+        assert self.pending is None
+        _RecordingScorer.log.append((self.name, "option", opt, value))
+
+    def round_csr_begin(self, strat, sel, point=None):
+        assert self.pending is None, "a second begin on a pending scorer"
+        self.round_count += 1
+        self.pending = object()
+        self._args = (strat, sel, np.array(point))
+        _RecordingScorer.log.append((self.name, "begin", strat, sel))
+        return self.pending
+
+    def round_csr_end(self, copy=False):
+        assert self.pending is not None
+        self.pending = None
+        strat, sel, _ = self._args
+        _RecordingScorer.log.append((self.name, "end", strat, sel))
+        w = min(sel, self.n)
+        z = np.zeros
+        return dict(idx=np.arange(w, dtype=np.int64), score=np.linspace(2000.0, 1001.0, w), lam=-np.ones(w), ks=np.full(w, 3, np.int32),
+                    set_inds=z((w, 5), np.int32), row_entry=np.arange(w, dtype=np.int32), indptr=np.arange(w + 1, dtype=np.int32) * 2,
+                    indices=z(2 * w, np.int32), values=z(2 * w), rhs=z(w), n_total=self.n, new_strat=strat,
+                    counters=dict(nb_violated=w, strong=w, violated=w, nb_positive=w))
+
+    def get_candidates(self, idx):
+        raise AssertionError("not needed")
+
+
+def test_the_second_list_of_a_qcqp_round_is_begun_with_the_first(monkeypatch):
+    """The pairing of cut_select_qcqp.py:64-76 as the mixin learns it, call by call, with recording scorers: round 1 runs the two
+    lists one after the other and notes the pair; from round 2 on the LONGER list (the follower here) is begun first, the short
+    leader's stream is prioritised once, and the follower's own call only ends its round; a follower asked about another point
+    drops the speculative round and the pair is unlearnt."""
+    from sdpcutsel_via_nn_amd import _capi
+    from sdpcutsel_via_nn_amd.cut_solver import CutSolver, _Binding
+    cs = CutSolver()
+    cs._nb_vars, cs._nb_lifted, cs._dim = 12, 78, 3
+    agg_a, agg_b = [([0, 1, 2],)] * 40, [([0, 1, 2],)] * 4000
+    sa, sb = _RecordingScorer("A", 40), _RecordingScorer("B", 4000)
+    ba, bb = _Binding(sa, agg_a, 12, 78), _Binding(sb, agg_b, 12, 78)
+    for b, agg in ((ba, agg_a), (bb, agg_b)):
+        b.n_at_bind, b.serial = len(agg), 0
+    cs._gpu_bindings = {id(agg_a): ba, id(agg_b): bb}
+    log = _RecordingScorer.log
+    del log[:]
+    rng = np.random.default_rng(0)
+
+    def round_(vv, second_point=None):
+        cs._agg_list = agg_a
+        cs._sel_eigcut_by_ordering_on_measure(2, vv, 1)
+        cs._agg_list = agg_b
+        cs._sel_eigcut_by_ordering_on_measure(1, vv if second_point is None else second_point, 1)
+
+    p1, p2, p3, p4 = (rng.random(90) for _ in range(4))
+    round_(p1)
+    assert [(e[0], e[1]) for e in log] == [("A", "begin"), ("A", "end"), ("B", "begin"), ("B", "end")]
+    assert ba.follower is not None and ba.follower[0] is bb and bb.leader is ba
+    del log[:]
+    round_(p2)
+    assert log[0] == ("A", "option", _capi.OPT_STREAM_PRIORITY, 1)
+    assert [(e[0], e[1]) for e in log[1:]] == [("B", "begin"), ("A", "begin"), ("A", "end"), ("B", "end")]
+    del log[:]
+    round_(p3)                                            # (the priority is set once)
+    assert [(e[0], e[1]) for e in log] == [("B", "begin"), ("A", "begin"), ("A", "end"), ("B", "end")]
+    del log[:]
+    round_(p4, second_point=p1)                           # the pattern breaks: B is asked about another point
+    assert [(e[0], e[1]) for e in log] == [("B", "begin"), ("A", "begin"), ("A", "end"), ("B", "end"), ("B", "begin"), ("B", "end")]
+    assert bb.wasted == 1 and ba.follower is None and bb.leader is None and sa.pending is None and sb.pending is None
+    # switched off: never paired
+    cs2 = CutSolver()
+    cs2._gpu_overlap = False
+    cs2._nb_vars, cs2._nb_lifted, cs2._dim = 12, 78, 3
+    ba2, bb2 = _Binding(_RecordingScorer("A", 40), agg_a, 12, 78), _Binding(_RecordingScorer("B", 4000), agg_b, 12, 78)
+    for b, agg in ((ba2, agg_a), (bb2, agg_b)):
+        b.n_at_bind, b.serial = len(agg), 0
+    cs2._gpu_bindings = {id(agg_a): ba2, id(agg_b): bb2}
+    for vv in (p1, p2):
+        cs2._agg_list = agg_a
+        cs2._sel_eigcut_by_ordering_on_measure(2, vv, 1)
+        cs2._agg_list = agg_b
+        cs2._sel_eigcut_by_ordering_on_measure(1, vv, 1)
+    assert ba2.follower is None and bb2.leader is None
+
+
+def test_count_above_from_the_head():
+    """RankList.count_above without a device: answered from the head when the list's order (and, under the combined strategy,
+    the marking rule of cut_select_qp.py:611) makes that exact; the full ranking is asked for otherwise (the fake raises)."""
+    rl, b, vv = _rank_list()                              # head scores 1009 .. 1005, 0.5, 0, -1, -2, -3 of a list of 50
+    assert rl.count_above(1000.0) == 5 and rl.count_above(0.25) == 6 and rl.count_above(-3.0) == 9
+    with pytest.raises(AssertionError):
+        rl.count_above(-3.5)                              # entries behind the head may exceed it: needs the complete ranking
+    rl2, _, _ = _rank_list(n_head=5)                      # a head of marked entries only (combined strategy)
+    assert rl2.count_above(1000.0) == 5                   # the entries behind it have obj_improve <= 1005 - 1000
+    with pytest.raises(AssertionError):
+        rl2.count_above(4.0)                              # ... which may well exceed 4
