@@ -260,6 +260,11 @@ int sdpcut_gather_scores_device(sdpcut_handle h, int64_t count, const void *d_id
  *   cols[c*SDPCUT_ROW_LD + .]  [L + i for i in set_inds] + Xarr_inds   (int64)
  *   ks[c]                      candidate size k (row length = k + k(k+1)/2)
  * A row is only meaningful when lam_min < -1e-15 (the reference skips the others).
+ * v = unit eigenvector of lam_min (numpy.linalg.eigh at cut_select_qp.py:796-797).  When the handle holds lam_min of the
+ * candidates at the current point (SDPCUT_EIG scored, e.g. by a feasibility / combined round) v comes from inverse iteration with
+ * that value (LU of A - lam I, residual a few ulp of ||A||), otherwise -- and whenever lam_min is multiple or within 1e-10 ||A|| of the
+ * next eigenvalue, where only an eigenSPACE is defined -- from a Jacobi iteration with vectors.  Either way the row is a unit
+ * eigenvector's cut; two solvers agree on it to eps / gap, as the reference's LAPACK and this library always did.
  */
 int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *lam_min,
                     double *coef, double *rhs, int64_t *cols, int32_t *ks);
