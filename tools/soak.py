@@ -36,6 +36,18 @@ def main():
     sc2.set_instance(n, wl["Q_arr"])
     sc2.set_candidates(wl["set_inds"][count // 3:count // 3 + min(count // 2, 300000)], wl["ks"][count // 3:count // 3 + min(count // 2, 300000)])
     pairs = 0
+    # (r3) a third handle with a list of several size classes (one launch for all of them, score_mfma_all_kernel)
+    rng3 = np.random.default_rng(5)
+    ks3 = rng3.choice(np.array([5, 5, 5, 5, 5, 5, 4, 3, 2], dtype=np.int32), size=70000)
+    S3 = np.full((70000, 5), -1, dtype=np.int32)
+    for kk in (2, 3, 4, 5):
+        m = np.flatnonzero(ks3 == kk)
+        S3[m, :kk] = synthetic.random_index_sets(n, kk, m.size, rng3)
+    sc3 = _capi.Scorer(0)
+    sc3.set_builtin_networks(5)
+    sc3.set_instance(n, wl["Q_arr"])
+    sc3.set_candidates(S3, ks3)
+    mixed = 0
     first, rounds, per_kind = {}, 0, {}
     t_end = time.time() + budget
     cur_size = None
@@ -71,6 +83,20 @@ def main():
             else:
                 sc.set_point(points[p])
                 r = sc.select_round(strat, sel, copy=False)
+            if rng.integers(0, 8) == 0:      # a round on the mixed list in between
+                p3, strat3, sel3 = int(rng.integers(0, len(points))), int(rng.choice([1, 2, 4])), int(rng.choice([64, 5000]))
+                r3 = sc3.round_csr(strat3, sel3, point=points[p3])
+                key3 = ("mixed list", p3, strat3, sel3)
+                got3 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r3.items()}
+                mixed += 1
+                if key3 not in first:
+                    first[key3] = got3
+                else:
+                    for k, v in got3.items():
+                        same = np.array_equal(v, first[key3][k], equal_nan=True) if isinstance(v, np.ndarray) else v == first[key3][k]
+                        if not same:
+                            print("MISMATCH round %d kind %s field %s" % (rounds, key3, k), flush=True)
+                            sys.exit(1)
             key = (size, p, strat, sel, csr)
             got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
             rounds += 1
@@ -86,12 +112,13 @@ def main():
                     sys.exit(1)
         if rounds % 2000 < 40:
             print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
-    fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc2.get_stat(_capi.STAT_SELECT_FALLBACKS)
+    fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc2.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc3.get_stat(_capi.STAT_SELECT_FALLBACKS)
     print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues; %d of them begun together with a round "
-          "on a second handle and ended after it), every repeat bit-identical; %d rounds answered by the path without in-kernel waits"
-          % (rounds, len(first), sizes, len(points), pairs, fallbacks))
+          "on a second handle and ended after it; + %d rounds on a list of mixed sizes 2..5), every repeat bit-identical; %d rounds answered by the path without in-kernel waits"
+          % (rounds, len(first), sizes, len(points), pairs, mixed, fallbacks))
     sc.close()
     sc2.close()
+    sc3.close()
 
 
 if __name__ == "__main__":
