@@ -428,6 +428,74 @@ def roofline(k, n_per_launch, kernel_ms, traffic, counts_digit=True, variant="mf
             "bytes_per_candidate": BYTES_PER_CAND[k], "issue": issue_floor(k, n_per_launch, kernel_ms, variant)}
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset, N > 1): THIS process -- which has made no GPU call and
+    never makes one -- builds the library once, starts N fresh children of this same script (one rank per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would), relays rank 0's one JSON line to stdout and
+    returns the worst child's exit code.  Children are separate processes started with fork + exec from a GPU-free parent: no
+    exec after a GPU call anywhere.  A rank that dies takes the others down with it (by pid) instead of leaving them in a
+    collective."""
+    import socket
+    import subprocess
+    from sdpcutsel_via_nn_amd import build as hip_build
+    hip_build.build(verbose=True)           # compile only: no dlopen, no GPU
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SDPCUT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # rank 0's stdout is read here (exactly one JSON line goes on); every other rank's stdout joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(ln.decode(errors="replace") for ln in procs[0].stdout), daemon=True)
+    reader.start()
+    worst, live = 0, list(procs)
+    deadline = None
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                if deadline is None:        # the others would wait for this rank in the next collective
+                    deadline = time.monotonic() + 5.0
+        if deadline is not None and live and time.monotonic() > deadline:
+            for p in live:
+                p.kill()
+            deadline = float("inf")
+    reader.join(timeout=10)
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines[-1:]:
+            sys.stderr.write(ln)
+    if json_lines:
+        sys.stdout.write(json_lines[-1] if json_lines[-1].endswith("\n") else json_lines[-1] + "\n")
+        sys.stdout.flush()
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
+# What a step should cost per rank at N = 8 (DESIGN.md section 6, from the one-GPU phase measurements under profiles/): a SCALE
+# line is to be held against this.  us per phase; "step_ms" is their sum (the host's enqueue calls overlap the score kernel).
+EXPECTED_8GPU = {
+    "c2": {"score_and_head_us": 385, "all_gather_us": [20, 35], "merge_and_rows_us": [26, 30], "host_tail_us": 15,
+           "step_ms": [0.45, 0.48], "aggregate_candidates_per_s": [1.65e10, 1.75e10], "weak_scaling_efficiency": [0.87, 0.93]},
+    "c4": {"score_and_head_us": 4160, "selection_tail_point_and_collective_us": 200, "step_ms": [4.4, 4.5],
+           "strong_scaling_efficiency_vs_one_gpu_step": 0.95},
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -457,6 +525,11 @@ def main():
     if args.config == "c3":
         return main_c3(args)
     cfg = CONFIGS[args.config]
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: be the launcher (before torch is imported, before anything touches a GPU)
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -464,9 +537,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                     % (args.gpus, args.gpus))
+        print("bench.py: --gpus %d differs from the launcher's WORLD_SIZE=%d; running with %d ranks" % (args.gpus, world, world),
+              file=sys.stderr)
+    if os.environ.get("SDPCUT_BENCH_LAUNCH_ONLY") == "1":
+        # launcher rehearsal without a GPU (tests/test_bench_contract.py, CPU): rendezvous over gloo, one collective, one line
+        if os.environ.get("SDPCUT_BENCH_FAIL_RANK") == str(rank):
+            sys.exit(3)
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print("a stray line from a native library")
+            print(json.dumps({"launch_only": True, "n_gpus": world, "rank_sum": int(t.item()), "steps": args.steps,
+                              "self_launched": os.environ.get("SDPCUT_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        dist.destroy_process_group()
+        return
     # rehearsal knobs (one-GPU box): SDPCUT_BENCH_BACKEND=gloo stages the all-gather through the
     # host, SDPCUT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
     backend = os.environ.get("SDPCUT_BENCH_BACKEND", "nccl")
@@ -669,6 +755,14 @@ def main():
         }
         if phases is not None:
             out["phases"] = phases
+        if use_dist:
+            out["config"]["collective_backend"] = backend
+            out["config"]["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0      # ranks of the RCCL communicator
+            out["config"]["launcher"] = "self (python bench.py --gpus N)" if os.environ.get("SDPCUT_BENCH_SELF_LAUNCHED") == "1" \
+                else "torch.distributed.run"
+            out["config"]["parallelism"] = "candidate shards x%d, one all-gather of per-shard heads per round" % world
+        if world > 1 and args.config in EXPECTED_8GPU:
+            out["expected_8gpu"] = dict(EXPECTED_8GPU[args.config], source="DESIGN.md section 6 (one-GPU phase measurements)")
         out["roofline"]["kernel_ms_samples"] = len(kernel_ms)
         out["config"]["selection_fallbacks"] = sc.get_stat(_capi.STAT_SELECT_FALLBACKS)       # rounds answered by the full-sort path
         out["roofline"]["traffic_source"] = ("profiles/score_kernel_traffic.json (rocprofv3 --pmc passes of this kernel at "

@@ -117,3 +117,54 @@ def test_bench_two_ranks_sharing_the_gpu(config, extra):
     assert d["scaling"] == ("weak" if config == "c2" else "strong")
     assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["value"] > 3e8          # two ranks time-share one GPU: roughly the one-GPU rate in total
+
+
+def _plain(args, env_extra, timeout=600):
+    """`python3 bench.py --gpus N ...` exactly as the driver's one-GPU command spells it: no launcher, WORLD_SIZE unset"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_plain_bench_gpus_n_launches_its_own_ranks(n):
+    """a bare `python bench.py --gpus N` used to exit non-zero.  Now the GPU-free parent starts N ranks, relays
+    rank 0's ONE JSON line (stray stdout lines go to stderr) and returns 0.  Rehearsed here without a GPU: the ranks only
+    rendezvous over gloo and run one collective (SDPCUT_BENCH_LAUNCH_ONLY)."""
+    out = _plain(["--gpus", str(n), "--steps", "5"], {"SDPCUT_BENCH_LAUNCH_ONLY": "1"})
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["rank_sum"] == n * (n + 1) // 2 and d["self_launched"] and d["steps"] == 5
+    assert "a stray line" in out.stderr.decode()
+
+
+def test_plain_bench_returns_the_worst_rank_exit_code_and_leaves_nobody_behind():
+    """a rank that dies: the launcher ends the others (they would wait in the collective for ever) and reports its code"""
+    import time
+    t0 = time.monotonic()
+    out = _plain(["--gpus", "3"], {"SDPCUT_BENCH_LAUNCH_ONLY": "1", "SDPCUT_BENCH_FAIL_RANK": "1"}, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stderr.decode()[-2000:])
+    assert not [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert time.monotonic() - t0 < 120
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,extra", [("c2", []), ("c4", ["--steps", "2"])])
+def test_plain_bench_gpus_2_on_the_one_gpu_box(config, extra):
+    """The exact form a SCALE run may use -- `python3 bench.py --gpus 2 --steps 5` -- on the one-GPU box: both ranks on cuda:0
+    (SDPCUT_BENCH_ONE_DEVICE=1), the all-gather through gloo.  rc 0, one JSON line, n_gpus 2, phases and the 8-GPU budget on it."""
+    out = _plain(["--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--config", config] + extra,
+                 {"SDPCUT_BENCH_ONE_DEVICE": "1", "SDPCUT_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    per_rank = 10 ** 6 if config == "c2" else 10 ** 8 // 2
+    assert d["n_gpus"] == 2 and d["config"]["candidates_per_gpu"] == per_rank
+    assert d["config"]["launcher"].startswith("self") and d["config"]["collective_backend"] == "gloo" and d["config"]["rccl_ranks"] == 0
+    assert abs(d["value"] - 2 * per_rank / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["value"] > 3e8
+    assert set(d["phases"]["device_us"]) == {"score_and_head", "all_gather", "merge_and_rows"}
+    assert "step_ms" in d["expected_8gpu"]
