@@ -529,10 +529,11 @@ class Scorer(object):
         """second half of a sharded round, enqueued without host synchronisation (sdpcut_shard_finish_enqueue);
         fields = 3: the records carry obj_improve as secondary key (SDPCUT_PART_COMBALL); pitch_words: distance between
         consecutive ranks' records when several lists share the gathered buffer (0 = one list per buffer)"""
-        self.round_count += 1
-        self._shard_pending = (int(world), int(sel_size), self.row_len)
+        # (the library refuses a second enqueue -- or any other stateful call -- before the wait: state changes only on success)
         self._check(self._lib.sdpcut_shard_finish_enqueue(self._h, int(world), int(count), int(fields), _vp(d_allrec_ptr),
                                                           int(pitch_words), int(sel_size), self.row_len))
+        self.round_count += 1
+        self._shard_pending = (int(world), int(sel_size), self.row_len)
 
     def shard_finish_wait(self, own=True):
         """-> dict(headers, idx, score, lam, coef, rhs, ks[, pos, n_own]): views of the handle's pinned block, which the

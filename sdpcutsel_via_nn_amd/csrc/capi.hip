@@ -66,7 +66,6 @@ int ensure_pinned(sdpcut_ctx *h, size_t bytes)
     return 0;
 }
 
-static void free_candidates(sdpcut_ctx *h);
 
 // Device arrays of a candidate list of N entries, cnt[k] of them with k variables (the callers
 // fill them: sdpcut_set_candidates from host arrays, the Philox generator and the cover
@@ -138,7 +137,7 @@ int sdpcut_create(int device_id, sdpcut_handle *out)
 
 } // extern "C"
 
-static void free_candidates(sdpcut_ctx *h)
+void free_candidates(sdpcut_ctx *h)
 {
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) {
         hipFree(h->bucket[k].d_set);
@@ -779,7 +778,7 @@ static int round_begin(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_
     if (!h->have_point || !h->d_eig) return sdpcut_fail(h, SDPCUT_ESTATE, "set_candidates and set_point first");
     if (coef_ld < h->row_len_max || coef_ld > SDPCUT_ROW_LD)
         return sdpcut_fail(h, SDPCUT_EINVAL, "coef_ld must hold the longest row (k + k(k+1)/2) and be <= SDPCUT_ROW_LD");
-    if (h->pend.active) return sdpcut_fail(h, SDPCUT_ESTATE, "a round is already pending on this handle: end it first");
+    SDPCUT_NO_PENDING(h);        // a fused round begun, or a sharded round enqueued and not waited for
     HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t need = strat == SDPCUT_STRAT_FEAS ? SDPCUT_EIG
                           : strat == SDPCUT_STRAT_OPT ? SDPCUT_NN : (SDPCUT_EIG | SDPCUT_NN);
@@ -827,6 +826,25 @@ static int round_begin(sdpcut_ctx *h, int strat, int64_t sel_size, int32_t coef_
     return SDPCUT_OK;
 }
 
+// round_csr_kernel's look-back over lower-indexed workgroups is bounded (CSR_SPIN_LIMIT): on a device shared with a kernel that
+// blocks it for long it gives up and sets hdr[10].  That is a transient condition, not an error of the round: by the time the
+// host sees the mark every workgroup of that launch has retired, so ONE more launch over the same head (ids and scores still
+// in the staging area) finds its predecessors' aggregates as soon as they are dispatched.  Counted like the selection's
+// fallbacks; only a second give-up fails the call.
+static int csr_again(sdpcut_ctx *h, int64_t cap, int64_t w, const int64_t *d_idx, const double *d_sc, int32_t coef_ld)
+{
+    int64_t *hdr = (int64_t *)h->pinned;
+    hdr[8] = hdr[9] = hdr[10] = 0;
+    ++h->stat_fallbacks;
+    const int64_t serial = ++h->round_serial;
+    int rc = launch_round_csr(h, cap, nullptr, w, d_idx, d_sc, coef_ld, h->pinned_dev, serial);
+    if (rc) return rc;
+    rc = wait_round_done(h, hdr + 7, serial);
+    if (rc) return rc;
+    if (hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out twice");
+    return SDPCUT_OK;
+}
+
 static int round_end(sdpcut_ctx *h, const void **block, int64_t *cap_out, int64_t *n_out, int64_t *n_total, int32_t *new_strat,
                      int64_t *counters)
 {
@@ -860,7 +878,10 @@ static int round_end(sdpcut_ctx *h, const void **block, int64_t *cap_out, int64_
         rc = wait_round_done(h, hdr + 7, P.serial);
         if (rc) return rc;
         have = rank_fast_finish(h, strat, sel_size, cap, (const int64_t *)h->pinned, &w, n_total, new_strat, counters) != 0;
-        if (have && csr && hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out");
+        if (have && csr && hdr[10] && w > 0) {      // the row assembly gave up its look-back (rows.hip): once more, see csr_again
+            rc = csr_again(h, cap, w, d_idx, d_sc, coef_ld);
+            if (rc) return rc;
+        }
     }
     ++h->stat_rounds;
     if (P.fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
@@ -879,7 +900,7 @@ static int round_end(sdpcut_ctx *h, const void **block, int64_t *cap_out, int64_
             if (rc) return rc;
             rc = wait_round_done(h, hdr + 7, serial);
             if (rc) return rc;
-            if (hdr[10]) return sdpcut_fail(h, SDPCUT_EHIP, "round_csr: look-back of the row assembly timed out");
+            if (hdr[10] && (rc = csr_again(h, cap, w, d_idx, d_sc, coef_ld))) return rc;
         } else if (w > 0) {
             rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
             if (rc) return rc;

@@ -61,10 +61,14 @@ struct PendingRound {
 };
 
 // every entry point that touches the handle's scores, staging or pinned block refuses to run between the two halves of a round
+// (fused: round_csr_begin / _end; sharded: shard_finish_enqueue / _wait -- their kernels are still writing d_stage and the pinned block)
 #define SDPCUT_NO_PENDING(h)                                                                                              \
     do {                                                                                                                  \
         if ((h)->pend.active)                                                                                             \
             return sdpcut_fail((h), SDPCUT_ESTATE, "a round begun with sdpcut_round_csr_begin is pending on this handle: end it first"); \
+        if ((h)->shard_pending_serial)                                                                                    \
+            return sdpcut_fail((h), SDPCUT_ESTATE, "a sharded round enqueued with sdpcut_shard_finish_enqueue is pending on this handle: " \
+                                                   "sdpcut_shard_finish_wait first");                                    \
     } while (0)
 
 struct sdpcut_ctx {
@@ -165,6 +169,7 @@ int ensure_stage(sdpcut_ctx *h, size_t bytes);   // capi.hip: grow h->d_stage
 // capi.hip: (re)allocate the device arrays of a list of N candidates, cnt[k] of them of size k
 int alloc_candidates(sdpcut_ctx *h, int64_t N, const int64_t cnt[SDPCUT_MAX_K + 1], int64_t global_base);
 int ensure_pinned(sdpcut_ctx *h, size_t bytes);  // capi.hip: grow h->pinned / h->pinned_dev
+void free_candidates(sdpcut_ctx *h);             // capi.hip: drop the handle's list (N = 0, nothing scored)
 
 #define HIP_TRY(h, expr)                                                                   \
     do {                                                                                   \

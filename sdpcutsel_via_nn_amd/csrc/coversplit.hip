@@ -113,11 +113,14 @@ extern "C" int sdpcut_set_candidates_cover_split(sdpcut_handle h_in, sdpcut_hand
     h->d_set_orig = nullptr;
     h->d_k = nullptr;
     auto cleanup = [&]() { hipFree(d_obj); hipFree(d_all); hipFree(d_kall); hipFree(d_flag); hipFree(d_v); hipFree(d_p); hipFree(d_tmp); };
+    // an error exit leaves BOTH handles without a list (N = 0, nothing scored): h_out's arrays have been taken out of it above
+    // and h_in still holds the whole objective cover -- a later round on either would run on half-built state
+    auto fail_cleanup = [&]() { cleanup(); free_candidates(h_in); free_candidates(h_out); };
 #define SPLIT_TRY(expr)                                                                         \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \
         if (e__ != hipSuccess) {                                                                \
-            cleanup();                                                                          \
+            fail_cleanup();                                                                     \
             return sdpcut_fail(h, SDPCUT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
         }                                                                                       \
     } while (0)
@@ -157,9 +160,9 @@ extern "C" int sdpcut_set_candidates_cover_split(sdpcut_handle h_in, sdpcut_hand
     // 2. the two lists
     SPLIT_TRY(sdpcut_sync(h));      // (the objective cover has left h_in's arrays)
     rc = alloc_candidates(h_in, tot[0], cnt[0], 0);
-    if (rc) { cleanup(); return sdpcut_fail(h, rc, std::string("cover_split: ") + sdpcut_last_error(h_in)); }
+    if (rc) { fail_cleanup(); return sdpcut_fail(h, rc, std::string("cover_split: ") + sdpcut_last_error(h_in)); }
     rc = alloc_candidates(h_out, tot[1], cnt[1], 0);
-    if (rc) { cleanup(); return rc; }
+    if (rc) { fail_cleanup(); return rc; }
     if (N_a > 0) {
         SplitSink sk{};
         sdpcut_ctx *hh[2] = {h_in, h_out};

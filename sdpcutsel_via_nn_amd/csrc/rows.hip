@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void round_csr_kernel(RoundCsrArgs R)
         pre_nnz += __shfl_xor(pre_nnz, off);
         gave_up |= __shfl_xor(gave_up, off);
     }
-    if (gave_up && lane == 0) R.o_hdr[10] = 1;      // the block is void; the host takes the synchronous path
+    if (gave_up && lane == 0) R.o_hdr[10] = 1;      // the block is void; the host launches the assembly once more (capi.hip: csr_again)
     if (keep) {
         const int64_t r = pre_rows + my_row;
         R.o_row_entry[r] = (int32_t)i;

@@ -67,6 +67,28 @@ class _RowStore(object):
             out.extend([b[0]] * b[1] if isinstance(b, tuple) else b)
         return out
 
+    def _tail(self, per_block, start, conv):
+        """arrays of the per-row attribute of the rows from ``start`` on: only the blocks behind ``start`` are touched"""
+        out, seen = [], 0
+        for b in per_block:
+            nb = b[1] if isinstance(b, tuple) else len(b)
+            skip = min(max(start - seen, 0), nb)
+            seen += nb
+            if skip < nb:
+                out.append(conv(b, skip))
+        return out
+
+    def rhs_from(self, start=0):
+        """right-hand sides of rows ``start``... as one float64 array (what a solve passes on: the rows added since the last)"""
+        parts = self._tail(self._rhs, start, lambda b, s: np.asarray(b[s:], dtype=np.float64))
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def senses_from(self, start=0):
+        """senses of rows ``start``... as an array of one-character strings"""
+        parts = self._tail(self._senses, start,
+                           lambda b, s: np.full(b[1] - s, b[0], dtype="<U1") if isinstance(b, tuple) else np.asarray(b[s:], dtype="<U1"))
+        return np.concatenate(parts) if parts else np.zeros(0, dtype="<U1")
+
     def get_num(self):
         return self._n
 
@@ -149,8 +171,8 @@ class LinearRelaxation(object):
         data, cols, lens = st.csr_parts(self._rows_passed)
         r = lens.shape[0]
         if r:
-            senses = np.asarray(st.senses[self._rows_passed:])
-            rhs = np.asarray(st.rhs[self._rows_passed:], dtype=np.float64)
+            senses = st.senses_from(self._rows_passed)          # (the list properties rebuild ALL rows: quadratic over the rounds)
+            rhs = st.rhs_from(self._rows_passed)
             inf = core.kHighsInf
             lower = np.where(senses == "L", -inf, rhs)
             upper = np.where(senses == "G", inf, rhs)
@@ -168,16 +190,16 @@ class LinearRelaxation(object):
 
     def solve(self):
         st = self.linear_constraints
-        assert np.all(np.isin(np.asarray(st.senses), ["G", "L", "E"]))
+        assert np.all(np.isin(st.senses_from(self._rows_passed if self._core is not None else 0), ["G", "L", "E"]))
         if self._core is not None:
             return self._solve_incremental()
         from scipy.optimize import linprog
         from scipy.sparse import csr_matrix
         nv = self.obj.shape[0]
         data, cols, lens = st.csr_parts()
-        senses = np.asarray(st.senses)
+        senses = st.senses_from(0)
         sign = np.where(senses == "G", -1.0, 1.0)
-        rhs = np.asarray(st.rhs, dtype=np.float64) * sign
+        rhs = st.rhs_from(0) * sign
         ptr = np.concatenate([[0], np.cumsum(lens)])
         A = csr_matrix((data * np.repeat(sign, lens), cols, ptr), shape=(lens.shape[0], nv))
         eq = senses == "E"

@@ -1,0 +1,55 @@
+"""Round 4, on the GPU through the C-ABI: what VERDICT r3 / ADVICE r3 asked for."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scorer(nv=40, count=20000, seed=23, k=3):
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    wl = synthetic.make_workload(nb_vars=nv, k=k, count=count, seed=seed)
+    sc = _capi.Scorer(0)
+    sc.set_network(k, *networks.load_network(k))
+    sc.set_instance(nv, wl["Q_arr"])
+    sc.set_candidates(wl["set_inds"], wl["ks"])
+    return sc, wl
+
+
+def test_sharded_round_pending_between_enqueue_and_wait_is_protected():
+    """between sdpcut_shard_finish_enqueue and sdpcut_shard_finish_wait the merge and rows kernels are still
+    writing d_stage and the pinned block; every stateful entry point -- set_point, a new head, a fused round, a second enqueue,
+    a new list -- must be refused (SDPCUT_ESTATE) and leave the pending round intact."""
+    import torch
+    from sdpcutsel_via_nn_amd import _capi
+    from sdpcutsel_via_nn_amd.distributed import DeviceOps
+    sc, wl = _scorer()
+    try:
+        ops = DeviceOps(sc, torch.device("cuda", 0))
+        vv, sel = wl["vars_values"], 500
+        sc.set_point(vv)
+        ref = ops.shard_finish(1, sel, ops.shard_head(1, sel), sel)
+        ref = {k: np.array(v) for k, v in ref.items()}
+        sc.set_point(vv)
+        rec = ops.shard_head(1, sel)
+        ops.shard_finish_enqueue(1, sel, rec, sel)
+        for name, call in (("set_point", lambda: sc.set_point(vv)),
+                           ("shard_head", lambda: ops.shard_head(1, sel)),
+                           ("second enqueue", lambda: ops.shard_finish_enqueue(1, sel, rec, sel)),
+                           ("round_csr_begin", lambda: sc.round_csr_begin(1, sel, point=vv)),
+                           ("select_round", lambda: sc.select_round(1, sel)),
+                           ("score", lambda: sc.score(_capi.EIG)),
+                           ("rank", lambda: sc.rank(1, sel, max_out=sel)),
+                           ("cut_rows", lambda: sc.cut_rows(np.arange(4))),
+                           ("set_candidates", lambda: sc.set_candidates(wl["set_inds"][:100], wl["ks"][:100]))):
+            with pytest.raises(_capi.SdpCutError, match="pending"):
+                call()
+                pytest.fail(name + " was not refused")
+        out = ops.shard_finish_wait()
+        w = out["n_own"]
+        assert w == sel and np.array_equal(out["idx"], ref["idx"]) and np.array_equal(out["score"], ref["score"])
+        assert np.array_equal(out["lam"][:w], ref["lam"]) and np.array_equal(out["coef"][:w], ref["coef"])
+        sc.set_point(vv)              # and the handle goes on as before
+        again = ops.shard_finish(1, sel, ops.shard_head(1, sel), sel)
+        assert np.array_equal(again["idx"], ref["idx"])
+    finally:
+        sc.close()
