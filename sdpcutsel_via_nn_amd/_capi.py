@@ -93,16 +93,31 @@ COMPAT_SYMBOLS = ["neural_net_2D", "neural_net_3D", "neural_net_4D", "neural_net
 _lib = None
 
 
+def _torch_installed():
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return sys.modules["torch"] is not None
+    try:
+        return importlib.util.find_spec("torch") is not None
+    except (ImportError, ValueError):
+        return False
+
+
 def load_library(path=None):
     """dlopen the HIP library; raises RuntimeError if it has not been built."""
     global _lib
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
-    # PyTorch-ROCm bundles its own HIP/HSA runtime (same SONAME libamdhip64.so.7).  A process
-    # must hold exactly one of them: import torch first so that this library binds to the
-    # runtime torch (device memory, streams, torch.distributed/RCCL) already brought in.
-    import torch  # noqa: F401
+    # PyTorch-ROCm bundles its own HIP/HSA runtime (same SONAME libamdhip64.so.7).  A process must hold exactly
+    # one of them: where torch is installed it is imported first, so that this library binds to the runtime torch
+    # (device memory, streams, torch.distributed/RCCL for the sharded rounds) brings in.  Where it is not -- the
+    # reference itself needs numpy and ctypes only (cut_select_qp.py:1-14, requirements.txt) -- the library binds to the
+    # system ROCm named in its RUNPATH: the single-GPU product has no torch dependency; `distributed.py` is the one
+    # module that imports it.
+    if _torch_installed():
+        import torch  # noqa: F401
     if not os.path.exists(path):
         raise RuntimeError(
             "%s not found: build it with `python -m sdpcutsel_via_nn_amd.build` "

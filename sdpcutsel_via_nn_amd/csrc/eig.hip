@@ -89,6 +89,13 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
     constexpr int D = P::D;
     Cand<K> cd;
     gather_candidate<K>(cd, s, A.vars, nullptr, A.nv, A.L, false);
+#if SDPCUT_LMIN
+    // (r4) Householder + Laguerre, Jacobi for the lanes it hands back: no re-packing (the lanes Jacobi is left with are a few
+    // per cent at structured vertices, none at generic points)
+    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd), out_idx, valid, tk_hist, c_viol);
+    (void)s_state; (void)s_out; (void)cnt;
+    return;
+#endif
     double a[D][D], v[D][D];
     fill_lifted<K>(a, cd.x, cd.X);
     const double tol = jacobi_tol<D, false>(a);
@@ -162,7 +169,7 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
             orig_nxt = A.orig[K][cc];
         }
         eig_tile<K, FUSE>(A, s_cur, out_idx, valid, s_state, s_out, &s_packed[par], tk_hist, c_viol);
-        if constexpr (SDPCUT_EIG_REPACK && EigPack<K>::CAP > 0) {
+        if constexpr (!SDPCUT_LMIN && SDPCUT_EIG_REPACK && EigPack<K>::CAP > 0) {
             // the next tile counts into the other word (zero since the barrier of the tile before this one); this tile's is
             // cleared behind the barrier that ends its use, in front of the barrier of the next tile
             __syncthreads();

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "jacobi.h"
+#include "lmin.h"
 
 // ------------------------------------------------------------------------------------------
 // gather of one candidate (cut_select_qp.py:529-540 record + :573-575 slices)
@@ -77,12 +78,28 @@ __device__ __forceinline__ void gather_candidate(Cand<K> &cd, const int32_t *set
     gather_candidate<K>(cd, s, vars, Q, nv, L, want_q);
 }
 
+// SDPCUT_LMIN = 1 (r4): lambda_min by Householder + Laguerre (lmin.h), Jacobi only for the lanes it hands back (multiple or
+// nearly multiple lambda_min); 0: Jacobi for everybody (rounds 1-3).
+#ifndef SDPCUT_LMIN
+#define SDPCUT_LMIN 1
+#endif
+
 template <int K>
 __device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
 {
     double a[K + 1][K + 1], v[K + 1][K + 1];
     fill_lifted<K>(a, cd.x, cd.X);
+#if SDPCUT_LMIN
+    bool ok;
+    double lam = lmin_laguerre<K + 1>(a, ok);
+    if (!ok) {      // (skipped by the whole wave when nobody needs it)
+        fill_lifted<K>(a, cd.x, cd.X);
+        jacobi_eig<K + 1, false>(a, v);
+        lam = diag_min<K + 1>(a);
+    }
+    return lam;
+#else
     jacobi_eig<K + 1, false>(a, v);
     return diag_min<K + 1>(a);
+#endif
 }
-

@@ -1,0 +1,197 @@
+// lambda_min ONLY of the (k+1)x(k+1) lifted matrices, one matrix per lane, in registers (round 4).
+//
+// What the scan of a round asks of the eigen-solver is ONE number per candidate -- numpy.linalg.eigvalsh(...)[0] at
+// cut_select_qp.py:796 (LAPACK: Householder tridiagonalisation dsytrd + eigenvalues-only QL dsterf).  Cyclic Jacobi
+// (jacobi.h) computes the whole spectrum: ~1170 VALU instructions per 4x4 matrix at 4.5 sweeps, ~2500 per 5x5, ~4500 per
+// 6x6, on the same fp64 pipe as the MLP's MFMAs.  Here:
+//
+//  1. Householder tridiagonalisation T = H^T A H (D - 2 reflections, backward stable: what dsytrd does).
+//  2. A certified lower bound of lambda_min(T) by block Gershgorin with the blocks {0,1}, {2}, ..., {D-1}: a lifted matrix
+//     [[1, x^T], [x, X]] ~ (1, x)(1, x)^T has ONE large eigenvalue, which the first reflection moves into the top 2x2
+//     block; the bound is ~0.05 below lambda_min where the trace bounds sit ~1 below.
+//  3. Laguerre's iteration on p(l) = det(T - l I) from that bound.  p, p', p'' come from the three-term recurrence
+//     p_i = (d_i - l) p_{i-1} - e_{i-1}^2 p_{i-2} (no divisions).  All roots are real, so from the left of the smallest one
+//     the iterates increase monotonically, never pass it, and converge cubically.  The recurrence is backward stable in
+//     Wilkinson's sense -- the computed p_i are the exact leading minors of a matrix within a few ulp of T - l I -- so left
+//     of lambda_min - c eps ||T|| every computed p_i is positive whatever the multiplicities: the limit is lambda_min(T)
+//     to a few ulp of ||T||, the accuracy class of LAPACK and of Jacobi (tools/lmin_proto.py: max |d| vs LAPACK
+//     1.2-2.0e-15 on the bench lists, against 1.3-2.0e-15 of LAPACK's own QL run on the same T).
+//     A step is "the last one" when the NEXT step of a cubically convergent sequence, step^4 / previous^3, is below
+//     1e-17, or when it is below a quarter ulp of ||T||: 3.3-3.7 evaluations per matrix, 4.8-5.2 per wave of 64.
+//  4. A multiple or nearly multiple lambda_min (exactly reducible T with equal eigenvalues in two blocks: a few per cent
+//     of the candidates at the McCormick vertex x = 0.5, X in {0, 0.5}, none at generic LP points) makes the convergence
+//     linear.  Such a lane gives up after LMIN_MAX_EVALS evaluations (ok = false) and the caller runs Jacobi on it --
+//     per lane: a candidate's lambda_min depends on its matrix alone, never on its neighbours in the wave.
+//
+// ~100 (Householder) + ~30 (bound) + ~45 per evaluation: ~340 instructions per 4x4 matrix, ~620 per 6x6.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "jacobi.h"
+
+#ifndef LMIN_MAX_EVALS
+#define LMIN_MAX_EVALS 8
+#endif
+
+// sqrt / reciprocal to ~2^-45 (hardware estimate 2^-23 + one Newton step): what a Laguerre step needs -- the step is a
+// correction, its error is multiplied by its own size
+__device__ __forceinline__ double lmin_sqrt_fast(double x)       // x > 0
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    return fma(fma(-g, g, x), 0.5 * y, g);
+}
+__device__ __forceinline__ double lmin_rcp_fast(double x)
+{
+    const double q = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, q, 1.0), q, q);
+}
+
+// T = H^T A H.  Reads and destroys the LOWER triangle of a (a[i][j], i >= j).  d: diagonal, e2: squared off-diagonals,
+// ea: their absolute values.
+template <int D>
+__device__ __forceinline__ void lmin_tridiagonalise(double (&a)[D][D], double (&d)[D], double (&e2)[D - 1], double (&ea)[D - 1])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < D - 2; ++c) {
+        const int m = D - 1 - c;                    // length of the column below the diagonal
+        const double x0 = a[c + 1][c];
+        double sig = 0.0;
+#pragma unroll
+        for (int i = c + 2; i < D; ++i) sig = fma(a[i][c], a[i][c], sig);
+        const double nrm2 = fma(x0, x0, sig);
+        const double nrm = jac_sqrt(nrm2 + 1e-300);                 // (+1e-300: a zero column stays finite)
+        e2[c] = nrm2;
+        ea[c] = nrm;
+        d[c] = a[c][c];
+        // v = x - alpha e_1 with alpha = -sign(x0) ||x|| (no cancellation), H = I - beta v v^T, beta = 2 / v^T v = -1 / (alpha v0)
+        const double alpha = -copysign(nrm, x0);
+        const double v0 = x0 - alpha;
+        // nothing to annihilate (the column is already tridiagonal; entries below 1e-140 are zero against a00 = 1): H = I
+        const double beta = sig > 1e-280 ? -jac_rcp(alpha * v0) : 0.0;
+        double v[D], p[D], w[D];
+        v[0] = v0;
+#pragma unroll
+        for (int i = 1; i < D; ++i) v[i] = (i < m) ? a[c + 1 + (i < m ? i : 0)][c] : 0.0;
+        // p = beta S v,  S = trailing block a[c+1.., c+1..] (symmetric, lower triangle stored)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (i < m) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j < m) {
+                        const double sij = (i >= j) ? a[c + 1 + i][c + 1 + j] : a[c + 1 + j][c + 1 + i];
+                        s = fma(sij, v[j], s);
+                    }
+                p[i] = beta * s;
+            }
+        }
+        double vp = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i < m) vp = fma(v[i], p[i], vp);
+        const double K = 0.5 * beta * vp;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i < m) w[i] = fma(-K, v[i], p[i]);
+        // S <- S - v w^T - w v^T
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                if (i < m) {
+                    double t = a[c + 1 + i][c + 1 + j];
+                    t = fma(-v[i], w[j], t);
+                    t = fma(-w[i], v[j], t);
+                    a[c + 1 + i][c + 1 + j] = t;
+                }
+    }
+    d[D - 2] = a[D - 2][D - 2];
+    d[D - 1] = a[D - 1][D - 1];
+    const double off = a[D - 1][D - 2];
+    e2[D - 2] = off * off;
+    ea[D - 2] = fabs(off);
+}
+
+// lambda_min of the symmetric matrix a (lower triangle read and destroyed).  ok = false: not converged within
+// LMIN_MAX_EVALS evaluations (or the start was not left of the spectrum, never observed) -- the caller runs Jacobi.
+template <int D>
+__device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
+{
+#pragma clang fp contract(off)
+    double d[D], e2[D - 1], ea[D - 1];
+    lmin_tridiagonalise<D>(a, d, e2, ea);
+    // ---- certified lower bound: block Gershgorin, blocks {0, 1}, {2}, ..., {D - 1}
+    double scale = fabs(d[0]);
+#pragma unroll
+    for (int i = 1; i < D; ++i) scale += fabs(d[i]);
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) scale = fma(2.0, ea[i], scale);
+    const double h = 0.5 * (d[0] + d[1]), g = 0.5 * (d[0] - d[1]);
+    const double rr = fma(g, g, e2[0]) + 1e-300;
+    const double r = rr * __builtin_amdgcn_rsq(rr);            // (2^-23 is plenty for a bound: the margin below covers it)
+    double lam = h - r;                                         // the smaller eigenvalue of the top 2 x 2 block
+    if constexpr (D > 2) {
+        lam -= ea[1];
+#pragma unroll
+        for (int i = 2; i < D; ++i) {
+            double gi = d[i] - ea[i - 1];
+            if (i < D - 1) gi -= ea[i];
+            lam = fmin(lam, gi);
+        }
+    }
+    lam = fma(-1e-6, scale, lam);
+    const double tol = 5.551115123125783e-17 * scale;          // a quarter ulp of ||T||
+    constexpr double n = (double)D, n1 = (double)(D - 1);
+    bool done = false, bad = false;
+    double prev3 = 0.0;
+#pragma unroll 1
+    for (int it = 0; it < LMIN_MAX_EVALS; ++it) {
+        // p, p', p'' of det(T - lam I) by the three-term recurrence (first rows written out: p_0 = 1, p_0' = p_0'' = p_1'' = 0,
+        // p_1' = -1); pos = all leading minors p_1 .. p_{D-1} positive (they are, left of lambda_min)
+        double pm2 = 1.0, pm1 = d[0] - lam;
+        double dm2 = 0.0, dm1 = -1.0;
+        double sm2 = 0.0, sm1 = 0.0;
+        bool pos = pm1 > 0.0;
+#pragma unroll
+        for (int i = 1; i < D; ++i) {
+            const double dl = d[i] - lam;
+            double p, dp, sp;
+            if (i == 1) {
+                p = fma(dl, pm1, -e2[0]);
+                dp = -(dl + pm1);
+                sp = 2.0;
+            } else if (i == 2) {
+                p = fma(dl, pm1, -(e2[1] * pm2));
+                dp = fma(dl, dm1, -pm1) + e2[1];
+                sp = fma(dl, 2.0, -2.0 * dm1);
+            } else {
+                p = fma(dl, pm1, -(e2[i - 1] * pm2));
+                dp = fma(-e2[i - 1], dm2, fma(dl, dm1, -pm1));
+                sp = fma(-e2[i - 1], sm2, fma(dl, sm1, -2.0 * dm1));
+            }
+            pm2 = pm1; pm1 = p;
+            dm2 = dm1; dm1 = dp;
+            sm2 = sm1; sm1 = sp;
+            if (i < D - 1) pos = pos & (p > 0.0);
+        }
+        // left of the spectrum every leading minor is positive; the first evaluation must find p itself positive too
+        bad = bad | (!done & (!pos | ((it == 0) & !(pm1 > 0.0))));
+        // Laguerre from the left: step = n p / (-p' + sqrt((n-1) ((n-1) p'^2 - n p p'')))
+        const double t = fma(n1 * dm1, dm1, -(n * pm1) * sm1);
+        const double den = lmin_sqrt_fast(fma(n1, fmax(t, 0.0), 1e-300)) - dm1;
+        double step = (n * pm1) * lmin_rcp_fast(den);
+        step = ((pm1 > 0.0) & (den > 0.0)) ? step : 0.0;           // p <= 0: at the root to rounding
+        const double s2 = step * step;
+        // the last step: below a quarter ulp of ||T||, or cubic convergence says the NEXT one would be (step^4 / previous^3 <= 1e-17)
+        const bool conv = (step <= tol) | (s2 * s2 <= prev3);
+        lam = done ? lam : lam + step;
+        prev3 = 1e-17 * (s2 * step);
+        done = done | conv;
+        if (!__any(!done & !bad)) break;
+    }
+    ok = done && !bad;
+    return lam;
+}

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "jacobi.h"
 #include "gather.h"
+#include "libm_exp.h"
 #include "topk_dev.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(64) void score_simple_kernel(ScoreArgs A)
                     double acc = 0.0;
                     for (int i = 0; i < fan_in; ++i) acc = acc + act[cur][i][lane] * W[j * fan_in + i];
                     acc = acc + b[j];
-                    act[cur ^ 1][j][lane] = 2.0 / (exp(acc * -2.0) + 1.0) + -1.0;
+                    act[cur ^ 1][j][lane] = 2.0 / (libm_exp(acc * -2.0) + 1.0) + -1.0;      // the host libm's exp: NNs.so's bits (libm_exp.h)
                 }
                 cur ^= 1;
                 fan_in = net.width;
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(64) void nn_batch_kernel(NetDev net, int64_t count,
             double acc = 0.0;
             for (int i = 0; i < fan_in; ++i) acc = acc + act[cur][i][lane] * W[j * fan_in + i];
             acc = acc + b[j];
-            act[cur ^ 1][j][lane] = 2.0 / (exp(acc * -2.0) + 1.0) + -1.0;
+            act[cur ^ 1][j][lane] = 2.0 / (libm_exp(acc * -2.0) + 1.0) + -1.0;      // the host libm's exp: NNs.so's bits (libm_exp.h)
         }
         cur ^= 1;
         fan_in = net.width;

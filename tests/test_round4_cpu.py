@@ -1,0 +1,82 @@
+"""Round 4, CPU side (no GPU needed)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_single_gpu_product_imports_and_binds_without_torch():
+    """the reference needs numpy + ctypes (cut_select_qp.py:1-14).  With torch masked from the import system the
+    package imports, the library loads against the system ROCm and a handle request reaches the device probe (SDPCUT_ENODEVICE
+    in the build container, a live handle on a GPU box); torch is never imported on the way."""
+    code = r'''
+import sys
+class _NoTorch(object):
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" or name.startswith("torch."):
+            raise ImportError("torch is masked for this test")
+sys.meta_path.insert(0, _NoTorch())
+sys.path.insert(0, %r)
+import sdpcutsel_via_nn_amd as pkg
+from sdpcutsel_via_nn_amd import _capi, cut_solver, harness, networks, synthetic
+lib = pkg.load_library()
+assert lib.sdpcut_version() >= 100
+try:
+    sc = pkg.Scorer(0)
+    sc.close()
+    print("handle ok")
+except pkg.SdpCutError as e:
+    assert "(-2)" in str(e) and "no CPU fallback" in str(e), str(e)
+    print("no device:", e)
+assert "torch" not in sys.modules, "torch was imported"
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    assert b"no device:" in out.stdout or b"handle ok" in out.stdout
+
+
+def _libm_exp_twin(x, T):
+    """Python twin of csrc/libm_exp.h (glibc's exp, the -mfma variant): exact fused multiply-adds through rational arithmetic"""
+    import struct
+    from fractions import Fraction
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def bits(v):
+        return struct.unpack("<Q", struct.pack("<d", v))[0]
+
+    def dbl(u):
+        return struct.unpack("<d", struct.pack("<Q", u & 0xFFFFFFFFFFFFFFFF))[0]
+    InvLn2N, Shift = float.fromhex("0x1.71547652b82fep0") * 128.0, float.fromhex("0x1.8p52")
+    hi, lo = float.fromhex("-0x1.62e42fefa0000p-8"), float.fromhex("-0x1.cf79abc9e3b3ap-47")
+    C2, C3, C4, C5 = (float.fromhex(h) for h in ("0x1.ffffffffffdbdp-2", "0x1.555555555543cp-3", "0x1.55555cf172b91p-5", "0x1.1111167a4d017p-7"))
+    kd = InvLn2N * x + Shift
+    ki = bits(kd)
+    kd -= Shift
+    r = fma(kd, lo, fma(kd, hi, x))
+    idx = 2 * (ki % 128)
+    tail, sbits = dbl(T[idx]), T[idx + 1] + (ki << 45)
+    r2 = r * r
+    tmp = fma(r2 * r2, fma(r, C5, C4), fma(r2, fma(r, C3, C2), tail + r))
+    scale = dbl(sbits)
+    return fma(scale, tmp, scale)
+
+
+def test_libm_exp_port_reproduces_the_host_libm_bit_for_bit():
+    """NNs.so's outputs are a function of the host libm's exp.  The port's table (recomputed by build.py) and
+    operation sequence give math.exp's bits on the range a tansig of the shipped networks can see (|2 n| <= 62.6) and beyond."""
+    import math
+    import random
+    from sdpcutsel_via_nn_amd import build
+    T = build.libm_exp_table()
+    assert len(T) == 256 and T[0] == 0 and T[1] == 0x3FF0000000000000
+    random.seed(5)
+    xs = [random.uniform(-63.0, 63.0) for _ in range(6000)] + [random.uniform(-1.0, 1.0) * 10.0 ** random.uniform(-12, 0) for _ in range(2000)]
+    xs += [0.0, -0.0, 1.0, -1.0, 62.6, -62.6, 1e-16, 511.9, -511.9]
+    bad = [x for x in xs if _libm_exp_twin(x, T) != math.exp(x)]
+    assert not bad, bad[:5]
