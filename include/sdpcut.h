@@ -97,10 +97,13 @@ enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, S
 
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier
- * timed out because other work kept its workgroups from starting, or a tie group overflowed the sort
- * buffers) and were answered by the full-sort path instead -- same result, ~1 ms instead of ~0.1 ms.
- * SDPCUT_STAT_SCORED = the measures (SDPCUT_EIG | SDPCUT_NN) scored at the current point. */
-enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3 };
+ * timed out because other work kept its workgroups from starting) and were answered by the full-sort
+ * path instead -- same result, ~1 ms instead of ~0.1 ms.
+ * SDPCUT_STAT_SCORED = the measures (SDPCUT_EIG | SDPCUT_NN) scored at the current point.
+ * SDPCUT_STAT_TIE_SPLITS (r4) = every-entry-visited combined rankings whose threshold group of EQUAL new scores
+ * did not fit the sort buffers (structured LP vertices) and was cut by its secondary key -- obj_improve, then index,
+ * cut_select_qp.py:601 under :625 -- with two more radix selections; until round 3 these rounds were fallbacks. */
+enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3, SDPCUT_STAT_TIE_SPLITS = 4 };
 int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value);
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */

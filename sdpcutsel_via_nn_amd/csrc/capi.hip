@@ -284,6 +284,7 @@ int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value)
     case SDPCUT_STAT_ROUNDS: *value = h->stat_rounds; return SDPCUT_OK;
     case SDPCUT_STAT_SELECT_FALLBACKS: *value = h->stat_fallbacks; return SDPCUT_OK;
     case SDPCUT_STAT_SCORED: *value = h->have_point ? (int64_t)h->scored : 0; return SDPCUT_OK;
+    case SDPCUT_STAT_TIE_SPLITS: *value = h->stat_tie_splits; return SDPCUT_OK;
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown statistic");
 }
@@ -884,7 +885,38 @@ static int round_end(sdpcut_ctx *h, const void **block, int64_t *cap_out, int64_
         }
     }
     ++h->stat_rounds;
-    if (P.fast_tried && !have && ((const int64_t *)h->pinned)[4]) ++h->stat_fallbacks;
+    bool resorted = false;      // the head in d_idx / d_sc was produced after the enqueued epilogue ran: launch it again
+    if (P.fast_tried && !have && strat == SDPCUT_STRAT_COMB && hdr[4] == 2 && hdr[6] == 4 /* TK_MODE_COMBALL */) {
+        // the threshold tie group of the every-entry-visited ranking does not fit the sort buffers (a structured LP vertex):
+        // cut it by its secondary key with two more selections (topk.hip: topk_tie_split) instead of sorting the full list
+        int64_t c7[7];
+        for (int i = 0; i < 7; ++i) c7[i] = hdr[i];
+        rc = topk_tie_split(h, cap, d_idx, d_sc, nullptr);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            c7[4] = 0;
+            have = rank_fast_finish(h, strat, sel_size, cap, c7, &w, n_total, new_strat, counters) != 0;
+            resorted = have;
+        }
+    }
+    if (P.fast_tried && !have && hdr[4]) ++h->stat_fallbacks;
+    if (resorted) {
+        if (h->timing > 1) HIP_TRY(h, hipEventRecord(h->ev[3], h->stream));
+        if (csr) {
+            hdr[8] = hdr[9] = hdr[10] = 0;
+            const int64_t serial = ++h->round_serial;
+            rc = launch_round_csr(h, cap, nullptr, w, d_idx, d_sc, coef_ld, h->pinned_dev, serial);
+            if (rc) return rc;
+            rc = wait_round_done(h, hdr + 7, serial);
+            if (rc) return rc;
+            if (hdr[10] && (rc = csr_again(h, cap, w, d_idx, d_sc, coef_ld))) return rc;
+        } else if (w > 0) {
+            rc = launch_cut_rows(h, w, nullptr, d_idx, h->base, d_lam, d_coef, coef_ld, d_rhs, nullptr, d_ks);
+            if (rc) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->pinned, h->d_stage, 64 + c * 8 * (4 + (size_t)coef_ld) + c * 4, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, sdpcut_sync(h));
+        }
+    }
     if (!have) {
         // general path (full sorts; the combined scan visiting every entry, or heads > 8192)
         // (the fast attempt above already counted the strong candidates: no second attempt)

@@ -88,7 +88,7 @@ struct sdpcut_ctx {
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     bool eig_kernel = true;        // SDPCUT_OPT_EIG_KERNEL: eigenvalue-only launches run eig_only_kernel (eig.hip)
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)
-    int64_t stat_rounds = 0, stat_fallbacks = 0;   // sdpcut_get_stat
+    int64_t stat_rounds = 0, stat_fallbacks = 0, stat_tie_splits = 0;   // sdpcut_get_stat
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed_score = false;      // ev[0] / ev[1] were attached to the last score launch
@@ -250,6 +250,8 @@ int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, 
                           double *d_score_out, int64_t cnt[5]);
 int topk_select_keys_on_device(sdpcut_ctx *h, int64_t n, int64_t k, int64_t *d_idx_out, double *d_val_out, int64_t cnt[5]);
 void free_topk_ws(sdpcut_ctx *h);
+// the void COMBALL selection in the handle's workspace, answered by two selections over precomputed keys (see topk.hip)
+int topk_tie_split(sdpcut_ctx *h, int64_t k, int64_t *d_idx_out, double *d_score_out, int64_t *k_eff_out);
 // the workspace NOT used by the selection enqueued last, and its size in 8-byte words: a later
 // kernel of the same stream may zero it and then set h->topk_alt_clean (saves the next memset)
 int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words);

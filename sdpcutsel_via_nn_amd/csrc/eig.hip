@@ -92,7 +92,7 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
 #if SDPCUT_LMIN
     // (r4) Householder + Laguerre, Jacobi for the lanes it hands back: no re-packing (the lanes Jacobi is left with are a few
     // per cent at structured vertices, none at generic points)
-    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd), out_idx, valid, tk_hist, c_viol);
+    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol);
     (void)s_state; (void)s_out; (void)cnt;
     return;
 #endif
@@ -182,7 +182,13 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
 #ifndef SDPCUT_EIG_W
 #define SDPCUT_EIG_W 6
 #endif
-template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? 8 : (KMAX == 4 ? SDPCUT_EIG_W : 5); };
+#ifndef SDPCUT_EIG_W3
+#define SDPCUT_EIG_W3 6
+#endif
+#ifndef SDPCUT_EIG_W5
+#define SDPCUT_EIG_W5 4
+#endif
+template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_EIG_W3 : (KMAX == 4 ? SDPCUT_EIG_W : SDPCUT_EIG_W5); };
 
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)

@@ -103,3 +103,54 @@ __device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd)
     return diag_min<K + 1>(a);
 #endif
 }
+
+// The same for the two hot kernels (eig_only_kernel, score_mfma_body).  The lanes Jacobi is left with go through a REAL function
+// call (noinline): they gather their matrix again from the index set -- same tables, same values, same lambda_min as the inline
+// form above -- so that neither x / X (k(k+3)/2 doubles, 40 registers at k = 5) nor Jacobi's own (k+1)^2 working set weigh on
+// the register allocation of the path every wave at a generic LP point takes.
+template <int K>
+__device__ __attribute__((noinline)) double candidate_eigmin_jacobi_cold(const int32_t *sp, const double *vars, int32_t nv, int64_t L)
+{
+    int32_t s[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) s[a] = sp[a];
+    Cand<K> again;
+    gather_candidate<K>(again, s, vars, nullptr, nv, L, false);
+    double a[K + 1][K + 1], v[K + 1][K + 1];
+    fill_lifted<K>(a, again.x, again.X);
+    jacobi_eig<K + 1, false>(a, v);
+    return diag_min<K + 1>(a);
+}
+
+template <int K>
+struct IndexSetArg { int32_t s[K]; };
+template <int K>
+__device__ __attribute__((noinline)) double candidate_eigmin_jacobi_cold(IndexSetArg<K> is, const double *vars, int32_t nv, int64_t L)
+{
+    Cand<K> again;
+    gather_candidate<K>(again, is.s, vars, nullptr, nv, L, false);
+    double a[K + 1][K + 1], v[K + 1][K + 1];
+    fill_lifted<K>(a, again.x, again.X);
+    jacobi_eig<K + 1, false>(a, v);
+    return diag_min<K + 1>(a);
+}
+
+template <int K>
+__device__ __forceinline__ double candidate_eigmin(const Cand<K> &cd, const int32_t (&s)[K], const double *vars, int32_t nv, int64_t L)
+{
+#if SDPCUT_LMIN
+    double a[K + 1][K + 1];
+    fill_lifted<K>(a, cd.x, cd.X);
+    bool ok;
+    double lam = lmin_laguerre<K + 1>(a, ok);
+    if (!ok) {
+        IndexSetArg<K> is;
+#pragma unroll
+        for (int i = 0; i < K; ++i) is.s[i] = s[i];
+        lam = candidate_eigmin_jacobi_cold<K>(is, vars, nv, L);
+    }
+    return lam;
+#else
+    return candidate_eigmin<K>(cd);
+#endif
+}

@@ -47,6 +47,17 @@ __device__ __forceinline__ double lmin_rcp_fast(double x)
     return fma(fma(-x, q, 1.0), q, q);
 }
 
+// Laguerre's step from the left of the smallest root of a real-rooted polynomial of degree n (n1 = n - 1):
+//   n p / (-p' + sqrt((n-1) ((n-1) p'^2 - n p p'')));  0 when p <= 0 (at the root to rounding)
+__device__ __forceinline__ double lmin_step(double n, double n1, double p, double dp, double sp)
+{
+#pragma clang fp contract(off)
+    const double t = fma(n1 * dp, dp, -(n * p) * sp);
+    const double den = lmin_sqrt_fast(fma(n1, fmax(t, 0.0), 1e-300)) - dp;
+    const double step = (n * p) * lmin_rcp_fast(den);
+    return ((p > 0.0) & (den > 0.0)) ? step : 0.0;
+}
+
 // T = H^T A H.  Reads and destroys the LOWER triangle of a (a[i][j], i >= j).  d: diagonal, e2: squared off-diagonals,
 // ea: their absolute values.
 template <int D>
@@ -115,8 +126,68 @@ __device__ __forceinline__ void lmin_tridiagonalise(double (&a)[D][D], double (&
     ea[D - 2] = fabs(off);
 }
 
+// ---- the cold part, OUT OF LINE: block-by-block iteration for numerically reducible T.  Couplings that are the rounding noise
+// of the reflections (relative deflation criterion, see lmin_laguerre) are zero: T is block diagonal there and lambda_min
+// is the smallest over the blocks.  Exactly this happens at the structured LP vertices (x = 0.5, X in {0, 0.5}: several per
+// cent of the candidates), where two blocks often SHARE their smallest eigenvalue -- a multiple root of det(T - l I), on which
+// Laguerre's iteration is only linear.  Block by block every root is simple: the recurrence restarts behind every split, every
+// block that closes contributes its own Laguerre step (degree nb), and the iterate moves by the smallest of them: a lower
+// bound of the distance to the smallest eigenvalue of ANY block, cubically convergent for the block that attains it,
+// indifferent to two blocks sharing it.  A real function call (noinline): the register allocation of the hot loop -- every
+// wave at a generic LP point -- does not see this code.  Returns NaN when it does not converge either.
+template <int D>
+struct LminBlocksIn {
+    double d[D], e2[D - 1], lam, tol;
+    unsigned smask;      // bit i: the coupling between rows i and i + 1 is treated as zero
+};
+
+template <int D>
+__device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
+{
+#pragma clang fp contract(off)
+    double lam = in.lam;
+    bool done = false, bad = false;
+#pragma unroll 1
+    for (int it = 0; it < 2 * LMIN_MAX_EVALS && !done && !bad; ++it) {
+        double pm2 = 0.0, pm1 = 1.0, dm2 = 0.0, dm1 = 0.0, sm2 = 0.0, sm1 = 0.0, nb = 0.0;
+        double amin = 1e300;
+        bool pos = true, fin = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double c = 0.0;
+            if (i > 0) {
+                const bool s = ((in.smask >> (i - 1)) & 1u) != 0u;
+                pm1 = s ? 1.0 : pm1;
+                dm1 = s ? 0.0 : dm1;
+                sm1 = s ? 0.0 : sm1;
+                nb = s ? 0.0 : nb;
+                c = s ? 0.0 : in.e2[i > 0 ? i - 1 : 0];
+            }
+            const double dl = in.d[i] - lam;
+            const double p = fma(dl, pm1, -(c * pm2));
+            const double dp = fma(-c, dm2, fma(dl, dm1, -pm1));
+            const double sp = fma(-c, sm2, fma(dl, sm1, -2.0 * dm1));
+            pm2 = pm1; pm1 = p;
+            dm2 = dm1; dm1 = dp;
+            sm2 = sm1; sm1 = sp;
+            nb += 1.0;
+            const bool close = (i == D - 1) ? true : (((in.smask >> i) & 1u) != 0u);
+            const double ab = lmin_step(nb, nb - 1.0, p, dp, sp);
+            amin = (close & (ab < amin)) ? ab : amin;
+            pos = pos & ((p > 0.0) | close);       // leading minors inside a block
+            fin = fin & ((p > 0.0) | !close);      // the blocks' own determinants
+        }
+        bad = !pos | ((it == 0) & !fin);
+        // (no cubic prediction here: it needs consecutive steps of ONE block; the iteration ends on a quarter ulp of ||T||)
+        done = amin <= in.tol;
+        lam += bad ? 0.0 : amin;
+    }
+    return (done && !bad) ? lam : __builtin_nan("");
+}
+
 // lambda_min of the symmetric matrix a (lower triangle read and destroyed).  ok = false: not converged within
-// LMIN_MAX_EVALS evaluations (or the start was not left of the spectrum, never observed) -- the caller runs Jacobi.
+// LMIN_MAX_EVALS evaluations (a NEARLY multiple lambda_min; or the start was not left of the spectrum, never observed) -- the
+// caller runs Jacobi.
 template <int D>
 __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
 {
@@ -145,10 +216,20 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
     lam = fma(-1e-6, scale, lam);
     const double tol = 5.551115123125783e-17 * scale;          // a quarter ulp of ||T||
     constexpr double n = (double)D, n1 = (double)(D - 1);
-    bool done = false, bad = false;
+    // A coupling is a split (lmin_blocks_cold) by the RELATIVE criterion of LAPACK's dsterf / dsteqr, e_i^2 <= (c eps)^2 |d_i d_{i+1}|
+    // (c = 4 here, 1 there): what the reflections leave of an exact zero between rows with O(1) diagonals goes; a coupling of
+    // 1e-15 between rows whose diagonals are themselves ~1e-15 -- the LP noise around an exactly singular block, which decides
+    // on which side of -1e-15 lambda_min falls (cut_select_qp.py:24, :647) -- stays, and such a lane ends with Jacobi as before.
+    unsigned smask = 0;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) smask |= (e2[i] <= 1.9721522630525295e-31 * fabs(d[i] * d[i + 1])) ? (1u << i) : 0u;
+    const bool has_split = smask != 0u;
+    // lanes with a split sit the hot loop out (done from the start) and go through the cold function behind it
+    bool done = has_split, bad = false;
     double prev3 = 0.0;
 #pragma unroll 1
     for (int it = 0; it < LMIN_MAX_EVALS; ++it) {
+        if (!__any(!done & !bad)) break;
         // p, p', p'' of det(T - lam I) by the three-term recurrence (first rows written out: p_0 = 1, p_0' = p_0'' = p_1'' = 0,
         // p_1' = -1); pos = all leading minors p_1 .. p_{D-1} positive (they are, left of lambda_min)
         double pm2 = 1.0, pm1 = d[0] - lam;
@@ -179,19 +260,24 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
         }
         // left of the spectrum every leading minor is positive; the first evaluation must find p itself positive too
         bad = bad | (!done & (!pos | ((it == 0) & !(pm1 > 0.0))));
-        // Laguerre from the left: step = n p / (-p' + sqrt((n-1) ((n-1) p'^2 - n p p'')))
-        const double t = fma(n1 * dm1, dm1, -(n * pm1) * sm1);
-        const double den = lmin_sqrt_fast(fma(n1, fmax(t, 0.0), 1e-300)) - dm1;
-        double step = (n * pm1) * lmin_rcp_fast(den);
-        step = ((pm1 > 0.0) & (den > 0.0)) ? step : 0.0;           // p <= 0: at the root to rounding
+        const double step = lmin_step(n, n1, pm1, dm1, sm1);
         const double s2 = step * step;
         // the last step: below a quarter ulp of ||T||, or cubic convergence says the NEXT one would be (step^4 / previous^3 <= 1e-17)
         const bool conv = (step <= tol) | (s2 * s2 <= prev3);
         lam = done ? lam : lam + step;
         prev3 = 1e-17 * (s2 * step);
         done = done | conv;
-        if (!__any(!done & !bad)) break;
     }
-    ok = done && !bad;
+    ok = done & !bad;
+    if (has_split) {      // (skipped by the whole wave when nobody needs it)
+        LminBlocksIn<D> in;
+#pragma unroll
+        for (int i = 0; i < D; ++i) in.d[i] = d[i];
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) in.e2[i] = e2[i];
+        in.lam = lam; in.tol = tol; in.smask = smask;
+        lam = lmin_blocks_cold<D>(in);
+        ok = lam == lam;
+    }
     return lam;
 }

@@ -272,7 +272,13 @@ int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, 
         int64_t c4[5] = {0, 0, 0, 0, 0};
         HIP_TRY(h, hipMemcpyAsync(c4, d_c4, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, sdpcut_sync(h));
-        if (!c4[4]) {       // (void: more equal new scores at the threshold than the sort buffers hold)
+        bool answered = !c4[4];
+        if (c4[4] == 2) {   // more equal new scores at the threshold than the sort buffers hold: cut the group by its secondary key
+            rc = topk_tie_split(h, max_out, d_idx_out, d_score_out, nullptr);
+            if (rc < 0) return rc;
+            answered = rc == 0;
+        }
+        if (answered) {
             const int64_t w = n < max_out ? n : max_out;
             h->last_total = -1;
             if (n_written) *n_written = w;

@@ -561,7 +561,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         PHASE_WAITMEM;
         PHASE_MARK(1);
         if (A.flags & SDPCUT_EIG) {
-            lam = candidate_eigmin<K>(cd);
+            lam = candidate_eigmin<K>(cd, s_cur, A.vars, A.nv, A.L);
             if (valid) A.eig_out[out_idx] = lam;
         }
         PHASE_MARK(2);

@@ -131,8 +131,9 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
         uint32_t it = 0;
         while (ld_u32(&ws->bar[b]) < nblocks) {
             __builtin_amdgcn_s_sleep(4);
-            if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
-                st_i64(&ws->counters[4], 1);
+            const int64_t gone = ld_i64(&ws->counters[4]);      // 2: the selection has declared itself void (tie group): leave, keep the 2
+            if (++it > TK_SPIN_LIMIT || gone) {
+                if (!gone) st_i64(&ws->counters[4], 1);
                 ok = 0;
                 break;
             }
@@ -228,8 +229,9 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 uint32_t it = 0;
                 while (ld_u32(&ws->ready[p]) == 0u) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++it > TK_SPIN_LIMIT || ld_i64(&ws->counters[4])) {
-                        st_i64(&ws->counters[4], 1);
+                    const int64_t gone = ld_i64(&ws->counters[4]);
+                    if (++it > TK_SPIN_LIMIT || gone) {
+                        if (!gone) st_i64(&ws->counters[4], 1);
                         ok = 0;
                         break;
                     }
@@ -1037,6 +1039,94 @@ int topk_select_keys_on_device(sdpcut_ctx *h, int64_t n, int64_t k, int64_t *d_i
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(cnt, ws->counters, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, sdpcut_sync(h));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The threshold tie group of the every-entry-visited combined ranking, cut by its SECONDARY key (r4).
+//
+// Mode COMBALL orders equal new scores by obj_improve, then index (the first stable sort of the reference,
+// cut_select_qp.py:601, under its second, :625), so a group of equal keys that straddles position k cannot be cut by
+// index.  As long as the whole group fits the sort buffers it is taken whole (resolve_digit); at a structured LP vertex --
+// round 1 of every BoxQP run under the combined strategy with fewer than sel strong candidates: x = 0.5, X in {0, 0.5},
+// thousands of candidates with the SAME -lambda_min -- it does not, the selection declares itself void (counters[4] = 2)
+// and, until round 3, a rocPRIM sort of the full list answered.  Now: the void selection has left the threshold key T, the
+// number of keys above it and the number `need` still wanted from the group in its workspace, and
+//     head = [ every key > T, ordered (key, obj_improve, index) ]  ++  [ top `need` of the group by (obj_improve, index) ]
+// -- two ordinary radix selections over precomputed keys: A keeps key > T (all of them are wanted: nothing to cut), B ranks
+// the group by the image of obj_improve and cuts ITS ties by index, which is exactly the reference's order.  Hand-written
+// path, no library sort, a few launches more than a normal round.
+__global__ __launch_bounds__(TK_THREADS) void tk_tiekeys_kernel(int64_t n, uint64_t T, int part, const double *eig, const double *obj,
+                                                                uint64_t *keys)
+{
+    for (int64_t i = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * TK_THREADS) {
+        const double o = obj[i];
+        const uint64_t key = masked_key(TK_MODE_COMBALL, eig[i], o);
+        keys[i] = part == 0 ? (key > T ? key : 0ull) : (key == T ? key_of(o) : 0ull);
+    }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_fillscore_kernel(double *out, int64_t count, uint64_t T)
+{
+    const int64_t i = (int64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+    if (i < count) out[i] = score_of(T);
+}
+
+// head of a ranking over the n precomputed keys in h->d_key_a (0 = not in the class); tie: equal keys by obj_improve, then
+// index (else by index).  Enqueued; *d_void receives the device address of the selection's void flag.
+static int select_prekeys_enqueue(sdpcut_ctx *h, int64_t n, int64_t k, bool tie, int64_t *d_idx_out, double *d_score_out,
+                                  const int64_t **d_void)
+{
+    int rc = topk_begin(h, nullptr, nullptr);
+    if (rc) return rc;
+    TopkWs *ws = (TopkWs *)h->d_topk_ws;
+    const int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
+    const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
+    hipLaunchKernelGGL(tk_prekeys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, h->d_key_a, ws);
+    *d_void = &ws->counters[4];
+    return topk_enqueue_after_pass0(h, ws, tie ? TK_MODE_COMBALL : TK_MODE_FEAS, n, k, 0.0, d_idx_out, d_score_out, false, 0,
+                                    h->base, TK_MAXK);
+}
+
+// h->d_topk_ws holds a COMBALL selection for a head of k entries that declared itself void because of its threshold tie
+// group (counters[4] == 2).  Writes the head (k_eff entries) to d_idx_out / d_score_out.
+// -> 0 done; 1 not applicable (another kind of void: the caller takes its general path); < 0 error.
+int topk_tie_split(sdpcut_ctx *h, int64_t k, int64_t *d_idx_out, double *d_score_out, int64_t *k_eff_out)
+{
+    const int64_t n = h->N;
+    if (!h->d_topk_ws || (h->scored & (SDPCUT_EIG | SDPCUT_NN)) != (SDPCUT_EIG | SDPCUT_NN) || k < 1 || k > TK_MAXK) return 1;
+    const TopkWs *ws = (const TopkWs *)h->d_topk_ws;
+    TkState st8;
+    int64_t c[8];
+    HIP_TRY(h, hipMemcpyAsync(&st8, &ws->state[8], sizeof(st8), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(c, ws->counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, sdpcut_sync(h));
+    const int64_t k_eff = c[3], need = st8.need, above = k_eff - need;
+    if (c[4] != 2 || c[6] != TK_MODE_COMBALL || need < 1 || above < 0 || k_eff > k) return 1;
+    const uint64_t T = st8.prefix;
+    int rc = ensure_rank_ws(h, n);
+    if (rc) return rc;
+    const int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
+    const int grid = (int)(nb < 4096 ? nb : 4096);
+    int64_t void_a = 0, void_b = 0;
+    const int64_t *d_void = nullptr;
+    if (above > 0) {
+        hipLaunchKernelGGL(tk_tiekeys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, T, 0, h->d_eig, h->d_obj, h->d_key_a);
+        rc = select_prekeys_enqueue(h, n, above, true, d_idx_out, d_score_out, &d_void);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(&void_a, d_void, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    hipLaunchKernelGGL(tk_tiekeys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, T, 1, h->d_eig, h->d_obj, h->d_key_a);
+    rc = select_prekeys_enqueue(h, n, need, false, d_idx_out + above, d_score_out + above, &d_void);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(&void_b, d_void, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(tk_fillscore_kernel, dim3((unsigned)((need + TK_THREADS - 1) / TK_THREADS)), dim3(TK_THREADS), 0, h->stream,
+                       d_score_out + above, need, T);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, sdpcut_sync(h));
+    if (void_a || void_b) return 1;      // a bounded wait expired (the GPU shared with a blocking kernel): the general path answers
+    ++h->stat_tie_splits;
+    if (k_eff_out) *k_eff_out = k_eff;
     return 0;
 }
 

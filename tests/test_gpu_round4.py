@@ -80,3 +80,124 @@ def test_nn_batch_and_compat_symbols_are_bit_identical_to_NNs_so(k):
         input_arr[:] = g["inputs"][i]
         assert func(input_arr) == g["nn_out"][i], (k, i)
     nn_library.NNs_terminate()
+
+
+def _mccormick_vertex(inst):
+    """the LP optimum of the McCormick relaxation of a BoxQP instance: x = 0.5, X_ii = 0.5, X_ij in {0, 0.5} by the sign of q_ij
+    (round 1 of every run of cut_select_qp.py:73-221)"""
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    Q = np.asarray(inst["Q_arr"], dtype=np.float64)
+    X = np.where(Q < 0, 0.5, 0.0)
+    iu = np.triu_indices(n)
+    X[iu[0] == iu[1]] = 0.5
+    return np.concatenate([X, np.full(n, 0.5)])
+
+
+@pytest.mark.parametrize("distinct", [0, 3])
+def test_structured_vertex_combined_round_stays_on_the_hand_written_path(oracle, distinct):
+    """VERDICT r3 item 3 (cut_select_qp.py:601, :606-623, :625): under the combined strategy with fewer than sel strong candidates
+    every entry is visited, and at a structured point thousands of candidates share ONE new score -lambda_min -- the threshold
+    group of the head exceeds the sort buffers.  Until round 3 the selection declared itself void and a library sort of the full
+    list answered (SDPCUT_STAT_SELECT_FALLBACKS; tools/soak.py's structured points: 9131 of 90750 rounds).  Now the group is cut
+    by its secondary key with two more radix selections (topk_tie_split): no fallback, and the head is the oracle's ranking of
+    the device's own scores, bit for bit.  The point: x = 0.5, X = 0.1 but for `distinct` rows (one lifted matrix -- one
+    eigenvalue -- shared by up to all candidates); the list: the candidates whose obj_improve is not positive there plus a few
+    dozen positive ones, so that fewer strong candidates exist than any head asks for."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    n = 100
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=300000, seed=7)
+    X = np.full((n, n), 0.1)
+    for v in range(distinct):
+        X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+    vv = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+    S, ks = wl["set_inds"], wl["ks"]
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(3)
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(S, ks)
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig0, obj0 = sc.get_scores()
+        keep = np.sort(np.concatenate([np.flatnonzero(obj0 <= 0), np.flatnonzero(obj0 > 0)[:60]]))
+        assert keep.size > 20000, keep.size
+        sc.set_candidates(S[keep], ks[keep])
+        N = keep.size
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.array_equal(eig, eig0[keep]) and np.array_equal(obj, obj0[keep])
+        n_strong = int(((obj > 0) & (eig < -1e-15)).sum())
+        assert n_strong <= 60
+        splits = 0
+        for sel in (500, 5000, 12000, 16384):
+            order, score, new_strat, cnt = oracle.rank_arrays(4, obj, eig, sel)
+            w = min(sel, N)
+            for route in ("round_csr", "select_round", "rank"):
+                before = sc.get_stat(_capi.STAT_TIE_SPLITS)
+                if route == "round_csr":
+                    r = sc.round_csr(4, sel, point=vv)
+                    ids, sco, ns = r["idx"], r["score"], r["new_strat"]
+                elif route == "select_round":
+                    r = sc.select_round(4, sel, point=vv)
+                    ids, sco, ns = r["idx"], r["score"], r["new_strat"]
+                else:
+                    ids, sco, _, ns, _ = sc.rank(4, sel, max_out=sel)
+                assert np.array_equal(ids, order[:w]), (route, sel, int((ids != order[:w]).sum()))
+                assert np.array_equal(sco, score[:w] + 0.0) and ns == new_strat, (route, sel)
+                splits += sc.get_stat(_capi.STAT_TIE_SPLITS) - before
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+        # the group of equal new scores at the threshold is larger than the sort buffers in at least one of these heads
+        vals, counts = np.unique(score, return_counts=True)
+        assert splits > 0, (n_strong, N, int(counts.max()))
+    finally:
+        sc.close()
+
+
+def test_lambda_min_of_a_candidate_does_not_depend_on_its_neighbours():
+    """csrc/lmin.h takes one of two loops per WAVE (some lane has a numerically reducible tridiagonal form or none has) and hands
+    single lanes to Jacobi: a candidate's lambda_min must be a function of its own matrix, bit for bit -- in any order of the list,
+    next to any neighbours, in the eigenvalue kernel and in every scoring kernel."""
+    import os
+    from conftest import GOLDEN
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, harness
+    inst = harness.parse_boxqp(os.path.join(GOLDEN, "instances", "spar070-050-1.in"))
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    g = np.load(os.path.join(GOLDEN, "rounds_spar070_050_1_d5_s4.npz"))
+    rng = np.random.default_rng(3)
+    # a structured point (splits, Jacobi lanes), the LP point of round 2 (a few of each), a late round (none)
+    points = [_mccormick_vertex(inst), g["r02_vars"], g["r12_vars"]]
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(5)
+        sc.set_instance(n, inst["Q_arr"])
+        N = sc.set_candidates_cover(inst["adj"], 5)
+        S, ks = sc.get_candidates(np.arange(N))
+        perm = rng.permutation(N)
+        res = {}
+        for tag, sets, kk in (("cover order", S, ks), ("shuffled", S[perm], ks[perm])):
+            sc.set_candidates(sets, kk)
+            for pi, vv in enumerate(points):
+                for kern in (_capi.KERNEL_MFMA, _capi.KERNEL_VALU):
+                    sc.set_option(_capi.OPT_KERNEL, kern)
+                    for eigk in (1, 0):
+                        sc.set_option(_capi.OPT_EIG_KERNEL, eigk)
+                        sc.set_point(vv)
+                        sc.score(_capi.EIG)
+                        e1 = sc.get_scores(obj=False)[0].copy()
+                        sc.set_point(vv)
+                        sc.score(_capi.EIG | _capi.NN)
+                        e2 = sc.get_scores()[0].copy()
+                        res[(tag, pi, kern, eigk)] = (e1, e2)
+        ref = res[("cover order", 0, _capi.KERNEL_MFMA, 1)][0]
+        for (tag, pi, kern, eigk), (e1, e2) in res.items():
+            base = res[("cover order", pi, _capi.KERNEL_MFMA, 1)][0]
+            if tag == "shuffled":
+                assert np.array_equal(e1, base[perm]) and np.array_equal(e2, base[perm]), (tag, pi, kern, eigk)
+            else:
+                assert np.array_equal(e1, base) and np.array_equal(e2, base), (tag, pi, kern, eigk)
+        assert ref.shape[0] == N
+    finally:
+        sc.close()

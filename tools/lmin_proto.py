@@ -107,25 +107,54 @@ def poly(d, e2, lam):
 
 
 K_MAX = int(os.environ.get("K_MAX", "8"))       # evaluations a lane gets; lanes that have not converged by then are left to Jacobi
+SPLIT = os.environ.get("SPLIT", "1") == "1"     # treat couplings below 2 ulp of ||T|| as zero: lambda_min = min over the blocks
+
+
+def lag_step(nb, p, dp, sp):
+    t = (nb - 1) * dp * dp - nb * p * sp
+    den = np.sqrt((nb - 1) * np.maximum(t, 0.0) + 1e-300) - dp
+    return np.where((p > 0) & (den > 0), nb * p / np.where(den > 0, den, 1.0), 0.0)
 
 
 def lambda_min(A, stats=None):
-    """-> (lam, ok): ok False = not converged within K_MAX evaluations (a multiple / nearly multiple lambda_min: linear convergence)"""
+    """-> (lam, ok): ok False = not converged within K_MAX evaluations (a nearly multiple lambda_min: linear convergence).
+    An exactly reducible T (couplings at rounding level: the structured LP vertices) is handled block by block: every block has
+    simple eigenvalues, the step is the smallest of the blocks' Laguerre steps -- a lower bound of the distance to the smallest
+    eigenvalue of ANY block, cubically convergent for the block that attains it, indifferent to two blocks sharing it."""
     d, e2, ea = tridiagonalise(A)
     B, n = d.shape
     lam, scale = lower_bound(d, e2, ea)
     tol = 0.25 * EPS * scale
+    # LAPACK's relative deflation criterion (dsterf: e^2 <= eps^2 |d_i d_{i+1}|), with 4 eps
+    split = (e2 <= (4 * 0.5 * EPS) ** 2 * np.abs(d[:, :-1] * d[:, 1:])) if SPLIT else np.zeros_like(e2, dtype=bool)
+    has_split = split.any(axis=1)
+    e2s = np.where(split, 0.0, e2)
     done = np.zeros(B, dtype=bool)
     prev3 = np.zeros(B)
     nev = np.zeros(B, dtype=int)
     for it in range(K_MAX):
-        p, dp, sp, pmin = poly(d, e2, lam)
+        pm2, pm1 = np.zeros(B), np.ones(B)
+        dm2, dm1 = np.zeros(B), np.zeros(B)
+        sm2, sm1 = np.zeros(B), np.zeros(B)
+        nb = np.zeros(B)
+        amin = np.full(B, np.inf)
+        for i in range(n):
+            if i > 0:
+                s = split[:, i - 1]
+                pm1, dm1, sm1, nb = np.where(s, 1.0, pm1), np.where(s, 0.0, dm1), np.where(s, 0.0, sm1), np.where(s, 0.0, nb)
+            c = e2s[:, i - 1] if i > 0 else 0.0
+            dl = d[:, i] - lam
+            p = dl * pm1 - c * pm2
+            dp = dl * dm1 - pm1 - c * dm2
+            sp = dl * sm1 - 2 * dm1 - c * sm2
+            pm2, pm1, dm2, dm1, sm2, sm1 = pm1, p, dm1, dp, sm1, sp
+            nb = nb + 1
+            close = np.ones(B, dtype=bool) if i == n - 1 else split[:, i]
+            amin = np.where(close, np.minimum(amin, lag_step(nb, p, dp, sp)), amin)
         nev[~done] += 1
-        t = (n - 1) * dp * dp - n * p * sp
-        den = np.sqrt((n - 1) * np.maximum(t, 0.0)) - dp
-        step = np.where((p > 0) & (den > 0), n * p / np.where(den > 0, den, 1.0), 0.0)
+        step = amin
         s2 = step * step
-        conv = (step <= tol) | (s2 * s2 <= prev3)          # cubic regime: the NEXT step would be ~ step^4 / previous^3 <= 1e-17
+        conv = (step <= tol) | (~has_split & (s2 * s2 <= prev3))
         lam = np.where(done, lam, lam + step)
         prev3 = 1e-17 * s2 * step
         done |= conv
@@ -134,6 +163,7 @@ def lambda_min(A, stats=None):
     if stats is not None:
         stats["evals"] = nev
         stats["notdone"] = int((~done).sum())
+        stats["split"] = int(has_split.sum())
     return lam, done
 
 
