@@ -5,7 +5,7 @@
 
 One "step" = one selection round over one batch of synthetic candidates whose index sets are
 resident in HBM, bracketed HOST TO HOST (SURVEY.md section 8 d): the LP point starts in a host
-array (`sdpcut_set_point`), every candidate is scored (Jacobi lambda_min + MLP optimality
+array (`sdpcut_set_point`), every candidate is scored (lambda_min: Householder + Laguerre, csrc/lmin.h; MLP optimality
 measure), ranked with the combined strategy (sel_size = 5000), the per-shard heads are merged
 (N > 1: one RCCL all-gather), the eigen-cut rows of the selected candidates are generated, and
 the round's results are back in host memory when the step ends.
@@ -119,7 +119,7 @@ def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
     # the reference's own shape -- a Python loop with one ctypes call
     # into the NNs.so-compatible entry point and one LAPACK eigvalsh per candidate -- on a small
     # sub-sample (optimality list + feasibility list = both measures for every candidate)
-    m = min(20000, sample)
+    m = min(100000, sample)      # SURVEY 8 d: N = 1e5 subsample
     agg = oracle.build_agg_list([tuple(int(v) for v in s) for s in si[:m]], nb_vars, Q)
     t1 = time.perf_counter()
     oracle.sel_eigcut_by_ordering_on_measure(agg, L, 2, vv)
@@ -275,6 +275,8 @@ def bench_c5(device_index, steps, warm=10):
             one()
         torch.cuda.synchronize()
         out["strategy_%d" % strat]["round_ms_lists_one_after_the_other"] = (time.perf_counter() - t0) / steps * 1e3
+    # speculative rounds of the follower pairing that nobody collected (cut_solver._Binding.drain); 0 in a loop that asks for both lists
+    out["wasted_speculative_rounds"] = int(sum(getattr(b, "wasted", 0) for b in cs._gpu_bindings.values()))
     sc_o.close()
     sc_c.close()
     return out
@@ -382,8 +384,34 @@ def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
                          "kernel": "eig_only_kernel<%d, true>" % K,      # <largest size class present, counts the selection's leading digit>
                          "kernel_ms": k_ms, "candidates_per_launch": n_local, "bytes_per_candidate": bytes_per,
                          "issue": issue_floor(K, n_local, k_ms, "eig"),
-                         "note": "gather + register Jacobi, no MLP: bound by VALU instruction issue (DESIGN.md section 5), "
-                                 "the HBM figure is the algorithmic one"}}
+                         "note": "gather + lambda_min in registers (Householder + Laguerre, csrc/lmin.h), no MLP: bound by VALU instruction "
+                                 "issue (DESIGN.md section 5), the HBM figure is the algorithmic one"}}
+
+
+def bench_opt_only(make_scorer, K, n_local, vv_host, steps):
+    """the optimality round (strategy 2, cut_select_qp.py:569-601: the paper's choice for dense instances) on the main workload: the MLP
+    without the eigenvalue, ranking by obj_improve, cut rows of the head (their lambda_min and eigenvector come from the epilogue)"""
+    import torch
+    from sdpcutsel_via_nn_amd import _capi
+    sc, _, _, _ = make_scorer(K, n_local, 7, 0)
+    for _ in range(30):
+        sc.select_round(2, SEL, copy=False, point=vv_host)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc.select_round(2, SEL, copy=False, point=vv_host)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sc.set_option(_capi.OPT_TIMING, 1)
+    ms = []
+    for _ in range(10):
+        sc.select_round(2, SEL, copy=False, point=vv_host)
+        ms.append(sc.last_timing()[0])
+    sc.close()
+    k_ms = float(np.mean(ms))
+    tflops = FLOPS_PER_CAND[K] * n_local / (k_ms * 1e-3) / 1e12
+    return {"value": n_local / dt, "unit": "candidates/s", "ms_per_step": dt * 1e3, "steps": steps, "strategy": 2,
+            "kernel_ms": k_ms, "achieved_TFLOPs": tflops, "roofline_frac": tflops / FP64_PEAK_TFLOPS}
 
 
 class _StdoutToStderr(object):
@@ -792,6 +820,7 @@ def main():
             out["secondary"] = sec
             # the feasibility round (strategy 1, cut_select_qp.py:639-654) on the same list: the eigenvalue-only kernel
             out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
+            out["secondary"]["strategy_2"] = bench_opt_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))

@@ -113,9 +113,12 @@ def main():
         if rounds % 2000 < 40:
             print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
     fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc2.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc3.get_stat(_capi.STAT_SELECT_FALLBACKS)
+    splits = [s_.get_stat(_capi.STAT_TIE_SPLITS) for s_ in (sc, sc2, sc3)]
     print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues; %d of them begun together with a round "
-          "on a second handle and ended after it; + %d rounds on a list of mixed sizes 2..5), every repeat bit-identical; %d rounds answered by the path without in-kernel waits"
-          % (rounds, len(first), sizes, len(points), pairs, mixed, fallbacks))
+          "on a second handle and ended after it; + %d rounds on a list of mixed sizes 2..5), every repeat bit-identical; %d rounds answered by the "
+          "full-sort path (SDPCUT_STAT_SELECT_FALLBACKS); %d / %d / %d rounds (first / second handle / mixed list) whose threshold tie group was "
+          "cut by its secondary key (SDPCUT_STAT_TIE_SPLITS)"
+          % (rounds, len(first), sizes, len(points), pairs, mixed, fallbacks, splits[0], splits[1], splits[2]))
     sc.close()
     sc2.close()
     sc3.close()
