@@ -141,16 +141,26 @@ struct LminBlocksIn {
     unsigned smask;      // bit i: the coupling between rows i and i + 1 is treated as zero
 };
 
+#ifndef SDPCUT_LMIN_BLOCKS_INLINE
+#define SDPCUT_LMIN_BLOCKS_INLINE 0
+#endif
 template <int D>
+#if SDPCUT_LMIN_BLOCKS_INLINE
+__device__ __forceinline__ double lmin_blocks_cold(const LminBlocksIn<D> &in)
+#else
 __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
+#endif
 {
 #pragma clang fp contract(off)
     double lam = in.lam;
     bool done = false, bad = false;
+    double prev3 = 0.0;
+    int prev_row = -1;
 #pragma unroll 1
-    for (int it = 0; it < 2 * LMIN_MAX_EVALS && !done && !bad; ++it) {
+    for (int it = 0; it < LMIN_MAX_EVALS + 2 && !done && !bad; ++it) {
         double pm2 = 0.0, pm1 = 1.0, dm2 = 0.0, dm1 = 0.0, sm2 = 0.0, sm1 = 0.0, nb = 0.0;
         double amin = 1e300;
+        int row = -1;      // last row of the block whose step is the smallest
         bool pos = true, fin = true;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -173,13 +183,19 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
             nb += 1.0;
             const bool close = (i == D - 1) ? true : (((in.smask >> i) & 1u) != 0u);
             const double ab = lmin_step(nb, nb - 1.0, p, dp, sp);
-            amin = (close & (ab < amin)) ? ab : amin;
+            const bool take = close & (ab < amin);
+            amin = take ? ab : amin;
+            row = take ? i : row;
             pos = pos & ((p > 0.0) | close);       // leading minors inside a block
             fin = fin & ((p > 0.0) | !close);      // the blocks' own determinants
         }
         bad = !pos | ((it == 0) & !fin);
-        // (no cubic prediction here: it needs consecutive steps of ONE block; the iteration ends on a quarter ulp of ||T||)
-        done = amin <= in.tol;
+        // the last step: a quarter ulp of ||T||, or -- when the SAME block gave the smallest step twice in a row, i.e. these are
+        // consecutive steps of one cubically convergent sequence -- the prediction that the next one would be below 1e-17
+        const double s2 = amin * amin;
+        done = (amin <= in.tol) | ((row == prev_row) & (s2 * s2 <= prev3));
+        prev3 = 1e-17 * (s2 * amin);
+        prev_row = row;
         lam += bad ? 0.0 : amin;
     }
     return (done && !bad) ? lam : __builtin_nan("");

@@ -53,11 +53,23 @@ __device__ __forceinline__ void cut_row_one(const int32_t *s5, const double *var
 #ifndef SDPCUT_ROWS_INVERSE_ITERATION
 #define SDPCUT_ROWS_INVERSE_ITERATION 1
 #endif
-    if (SDPCUT_ROWS_INVERSE_ITERATION && lam_known) {
+    if (SDPCUT_ROWS_INVERSE_ITERATION && (lam_known || SDPCUT_LMIN)) {
         // the scoring pass has computed lambda_min of this candidate (the value the selection ranked by): its eigenvector by
-        // inverse iteration (jacobi.h: ~700 instead of ~6700 instructions of a wave that has its SIMD to itself)
-        lam = *lam_known;
-        have = min_eigvec_known<D>(a, lam, ev) <= 1e-12;
+        // inverse iteration (jacobi.h: ~700 instead of ~6700 instructions of a wave that has its SIMD to itself).  (r4) A round
+        // that ranked without eigenvalues (optimality; explicit sdpcut_cut_rows on an unscored list) computes lambda_min here
+        // with the solver the scoring kernels use (lmin.h) instead of running Jacobi with vectors for the whole spectrum.
+        bool ok = true;
+        if (lam_known) {
+            lam = *lam_known;
+        } else {
+            double b[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) b[i][j] = a[i][j];
+            lam = lmin_laguerre<D>(b, ok);
+        }
+        have = ok && min_eigvec_known<D>(a, lam, ev) <= 1e-12;
 #ifdef SDPCUT_ABL_NOFALLBACK      // timing experiment (tools/build_ablation.sh, ABL_SRC=rows): wrong on multiple eigenvalues
         have = true;
 #endif

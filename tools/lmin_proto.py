@@ -132,12 +132,14 @@ def lambda_min(A, stats=None):
     done = np.zeros(B, dtype=bool)
     prev3 = np.zeros(B)
     nev = np.zeros(B, dtype=int)
-    for it in range(K_MAX):
+    prev_row = np.full(B, -1)
+    for it in range(K_MAX + 2):
         pm2, pm1 = np.zeros(B), np.ones(B)
         dm2, dm1 = np.zeros(B), np.zeros(B)
         sm2, sm1 = np.zeros(B), np.zeros(B)
         nb = np.zeros(B)
         amin = np.full(B, np.inf)
+        row = np.full(B, -1)
         for i in range(n):
             if i > 0:
                 s = split[:, i - 1]
@@ -150,16 +152,21 @@ def lambda_min(A, stats=None):
             pm2, pm1, dm2, dm1, sm2, sm1 = pm1, p, dm1, dp, sm1, sp
             nb = nb + 1
             close = np.ones(B, dtype=bool) if i == n - 1 else split[:, i]
-            amin = np.where(close, np.minimum(amin, lag_step(nb, p, dp, sp)), amin)
+            ab = lag_step(nb, p, dp, sp)
+            take = close & (ab < amin)
+            amin, row = np.where(take, ab, amin), np.where(take, i, row)
         nev[~done] += 1
         step = amin
         s2 = step * step
-        conv = (step <= tol) | (~has_split & (s2 * s2 <= prev3))
+        conv = (step <= tol) | ((row == prev_row) & (s2 * s2 <= prev3))      # (prediction: consecutive steps of ONE block)
         lam = np.where(done, lam, lam + step)
-        prev3 = 1e-17 * s2 * step
+        prev3 = np.where(done, prev3, 1e-17 * s2 * step)
+        prev_row = np.where(done, prev_row, row)
         done |= conv
-        if done.all():
+        # lanes without a split have K_MAX evaluations (the device's hot loop), lanes with one K_MAX + 2 (its block loop)
+        if it >= K_MAX - 1 and not (has_split & ~done).any():
             break
+    done &= has_split | (nev <= K_MAX)
     if stats is not None:
         stats["evals"] = nev
         stats["notdone"] = int((~done).sum())
