@@ -433,8 +433,10 @@ class _StdoutToStderr(object):
 # 10^6 candidates; a VALU instruction occupies its SIMD for 4 cycles, a quarter-rate transcendental for 16, an fp64 MFMA for 64):
 # what the kernel would take if its SIMDs never waited.  Not a roofline in the HBM / MFMA sense -- the bound these kernels run into.
 ISSUE_CYCLES_PER_CAND = {
-    ("eig", 3): ((18.67 - 1.26) * 4 + 1.26 * 16, "profiles/r03_eig_k3_kernel_pmc.txt"),
-    ("mfma", 3): ((5357 * 4 + 348 * 64) / 64.0, "profiles/r03_k3_score_kernel_pmc.txt (83.71 M VALU + 5.4375 M MFMA per launch = 5357 + 348 per 64-candidate strip)"),
+    # (r4, Householder + Laguerre lambda_min) VALU instructions per launch, of which quarter-rate transcendentals, MFMAs:
+    ("eig", 3): ((7.807 - 0.229) * 4 + 0.229 * 16, "profiles/r04_eig_k3_kernel_pmc.txt (7.807 M VALU of which 0.229 M v_rsq / v_rcp_f64; round 3, Jacobi: 18.67 M)"),
+    ("mfma", 3): ((73.550 - 0.995) * 4 + 0.995 * 16 + 5.4375 * 64, "profiles/r04_k3_score_kernel_pmc.txt (73.55 M VALU of which 0.995 M transcendental + 5.4375 M MFMA "
+                                                                   "per launch = 4707 + 348 per 64-candidate strip; round 3: 83.71 M VALU = 5357 per strip)"),
 }
 SIMDS, CLOCK_GHZ = 1024, 2.4
 

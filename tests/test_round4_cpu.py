@@ -80,3 +80,66 @@ def test_libm_exp_port_reproduces_the_host_libm_bit_for_bit():
     xs += [0.0, -0.0, 1.0, -1.0, 62.6, -62.6, 1e-16, 511.9, -511.9]
     bad = [x for x in xs if _libm_exp_twin(x, T) != math.exp(x)]
     assert not bad, bad[:5]
+
+
+def _proto():
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import lmin_proto
+    return lmin_proto
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_lambda_min_solver_numerics_against_lapack(oracle, k):
+    """The algorithm of csrc/lmin.h (Householder + block Gershgorin start + Laguerre; numpy twin tools/lmin_proto.py, same operations
+    up to fused multiply-adds) against what the reference calls (cut_select_qp.py:796, eigvalsh UPLO="U"): same accuracy class as
+    LAPACK itself (<= 3e-15 on matrices of norm 2-4; the parity bound is 2e-13), same classification at -1e-15, no lane left to
+    Jacobi on a generic point, <= 8 evaluations."""
+    P = _proto()
+    from sdpcutsel_via_nn_amd import synthetic
+    nv = 60
+    wl = synthetic.make_workload(nb_vars=nv, k=k, count=20000, seed=11 + k)
+    L = nv * (nv + 1) // 2
+    si, vv = wl["set_inds"][:, :k], wl["vars_values"]
+    A = P.lifted(vv[L:][si], vv[:L][oracle.triu_positions(si, nv)], k)
+    ref = np.linalg.eigvalsh(A, UPLO="U")[:, 0]
+    st = {}
+    lam, ok = P.lambda_min(A, st)
+    assert ok.sum() >= ok.size - 2                     # (a nearly multiple lambda_min is left to Jacobi: none or a stray one here)
+    assert np.abs(lam - ref)[ok].max() <= 3e-15
+    assert np.array_equal((lam < -1e-15)[ok], (ref < -1e-15)[ok])
+    assert st["evals"].max() <= P.K_MAX + 2 and st["evals"].mean() < 4.5
+
+
+def test_lambda_min_solver_at_structured_vertices(oracle, golden_boxqp):
+    """McCormick vertices (x = 0.5, X in {0, 0.5}): reducible tridiagonal forms are iterated block by block, exactly singular ones
+    (zero diagonal: the relative deflation criterion never fires) and nearly multiple eigenvalues go to Jacobi -- a few per cent."""
+    P = _proto()
+    g = golden_boxqp
+    for tag in ("spar020_100_1_d3", "spar020_100_1_d4", "spar030_060_1_d3"):
+        S, ks, n = g[tag + "_set_inds"], g[tag + "_k"], int(g[tag + "_nb_vars"])
+        L = n * (n + 1) // 2
+        vv = g[tag + "_mck_vars"]
+        for k in np.unique(ks):
+            si = S[ks == k][:, :k]
+            A = P.lifted(vv[L:][si], vv[:L][oracle.triu_positions(si, n)], int(k))
+            ref = np.linalg.eigvalsh(A, UPLO="U")[:, 0]
+            st = {}
+            lam, ok = P.lambda_min(A, st)
+            assert (~ok).mean() <= 0.05, (tag, k, int((~ok).sum()))
+            assert np.abs(lam - ref)[ok].max() <= 3e-15
+            assert np.array_equal((lam < -1e-15)[ok], (ref < -1e-15)[ok]), (tag, k)
+            assert st["split"] > 0
+
+
+def test_exact_eigenvalue_tool_on_a_known_matrix():
+    """tools/lmin_truth.py (rational characteristic polynomial + 80-digit Newton): the noise-floor evidence rests on it"""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import lmin_truth
+    A = np.array([[2.0, 1.0, 0.0], [1.0, 2.0, 1.0], [0.0, 1.0, 2.0]])          # eigenvalues 2 - sqrt 2, 2, 2 + sqrt 2
+    t = lmin_truth.exact_lambda_min(A, 0.5)
+    from decimal import Decimal
+    assert abs(t - (Decimal(2) - Decimal(2).sqrt())) < Decimal(10) ** -50

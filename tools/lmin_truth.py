@@ -77,5 +77,37 @@ def main():
               % (sys.argv[1], r, k, m.size, el.mean(), el.max(), ep.mean(), ep.max(), int((~ok).sum())), flush=True)
 
 
+def pairs():
+    """the neighbours of the recorded feasibility rankings that the solvers order differently: exact values of both members"""
+    import lmin_proto as P
+    from sdpcutsel_via_nn_amd import _capi, harness
+    from oracle import cutsel_oracle as oracle
+    gold = os.path.join(ROOT, "tests", "golden")
+    for fn, r, prs in (("rounds_spar125_075_1_d4_s4", 5, [(806014, 803286)]),
+                       ("rounds_spar125_075_2_d3_s4", 18, [(26294, 53769), (21539, 126939), (82, 129580)])):
+        g = np.load(os.path.join(gold, fn + ".npz"))
+        name, dim = str(g["name"]), int(g["dim"])
+        inst = harness.parse_boxqp(os.path.join(gold, "instances", name + ".in"))
+        n, L = inst["nb_vars"], inst["nb_lifted"]
+        S, ks, N = _capi.enumerate_cover(inst["adj"], dim)
+        vv = g["r%02d_vars" % r]
+        for pr in prs:
+            vals = []
+            for i in pr:
+                k = int(ks[i])
+                si = S[i:i + 1, :k]
+                A = P.lifted(vv[L:][si], vv[:L][oracle.triu_positions(si, n)], k)[0]
+                lapL, lapU = np.linalg.eigvalsh(A, UPLO="L")[0], np.linalg.eigvalsh(A, UPLO="U")[0]
+                t = exact_lambda_min(A, lapU)
+                vals.append((i, lapU, lapL, t))
+                print("%s round %d candidate %7d (%d variables): exact %s   LAPACK 'U' (the reference's call) %.17e (%+.2e)   LAPACK 'L' %+.2e"
+                      % (fn, r, i, k, "%.24E" % t, lapU, float(Decimal(float(lapU)) - t), float(Decimal(float(lapL)) - t)))
+            print("    exact difference first - second %.3e;  LAPACK 'U' difference %.3e, 'L' difference %.3e"
+                  % (float(vals[0][3] - vals[1][3]), vals[0][1] - vals[1][1], vals[0][2] - vals[1][2]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pairs":
+        pairs()
+    else:
+        main()
