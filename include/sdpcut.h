@@ -206,7 +206,9 @@ int sdpcut_set_point_device(sdpcut_handle h, const void *d_vars_values);
 /*
  * Score every candidate at the current point (replaces the per-candidate loop bodies of
  * _sel_eigcut_by_ordering_on_measure, cut_select_qp.py:570-582 and :642-648):
- *   SDPCUT_EIG: eigmin[i]      = lambda_min([[1, x^T],[x, X]])          (a6)
+ *   SDPCUT_EIG: eigmin[i]      = lambda_min([[1, x^T],[x, X]])          (a6; numpy.linalg.eigvalsh(...)[0] at cut_select_qp.py:796.
+ *               (r4) Householder tridiagonalisation + Laguerre's iteration, Jacobi for nearly multiple lambda_min (csrc/lmin.h):
+ *               as far from the exact eigenvalue as LAPACK is, ~1e-16 on average, <= 2e-15 against LAPACK on matrices of norm 2-4)
  *   SDPCUT_NN : obj_improve[i] = (-S) * max_elem + nn([x | Q_slice]) * max_elem  (a4, a5)
  * Results stay on the device; fetch with sdpcut_get_scores.
  */
@@ -263,10 +265,11 @@ int sdpcut_gather_scores_device(sdpcut_handle h, int64_t count, const void *d_id
  *   cols[c*SDPCUT_ROW_LD + .]  [L + i for i in set_inds] + Xarr_inds   (int64)
  *   ks[c]                      candidate size k (row length = k + k(k+1)/2)
  * A row is only meaningful when lam_min < -1e-15 (the reference skips the others).
- * v = unit eigenvector of lam_min (numpy.linalg.eigh at cut_select_qp.py:796-797).  When the handle holds lam_min of the
- * candidates at the current point (SDPCUT_EIG scored, e.g. by a feasibility / combined round) v comes from inverse iteration with
- * that value (LU of A - lam I, residual a few ulp of ||A||), otherwise -- and whenever lam_min is multiple or within 1e-10 ||A|| of the
- * next eigenvalue, where only an eigenSPACE is defined -- from a Jacobi iteration with vectors.  Either way the row is a unit
+ * v = unit eigenvector of lam_min (numpy.linalg.eigh at cut_select_qp.py:796-797): inverse iteration with lam_min (LU of
+ * A - lam I, residual a few ulp of ||A||) -- the value the handle holds for the candidate at the current point (SDPCUT_EIG scored,
+ * e.g. by a feasibility / combined round) or, (r4) when it holds none, the value the same solver computes on the spot
+ * (Householder + Laguerre, csrc/lmin.h).  Whenever lam_min is multiple or within 1e-10 ||A|| of the next eigenvalue, where only an
+ * eigenSPACE is defined, v comes from a Jacobi iteration with vectors.  Either way the row is a unit
  * eigenvector's cut; two solvers agree on it to eps / gap, as the reference's LAPACK and this library always did.
  */
 int sdpcut_cut_rows(sdpcut_handle h, int64_t count, const int64_t *idx, double *lam_min,
@@ -467,9 +470,9 @@ int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double 
  * first neural_net_kD call creates it if needed.  Without a gfx950 device the functions report
  * once on stderr and return NaN -- there is no CPU fallback (SURVEY.md section 8 b lists "CPU twins of each"
  * entry point: deliberately absent).
- * NOT bit-identical to NNs.so: same operation order, but exp comes from the ROCm device library instead of the
- * host's libm -- 15-86 % of the outputs (5D ... 2D) agree to the last bit, the rest to 5e-14 (tested to 1e-12 relative against the
- * values captured from the real NNs.so; profiles/r03_accuracy.txt).
+ * (r4) BIT-IDENTICAL to NNs.so: the reference's summation order without contraction, and exp evaluated as the host libm evaluates it
+ * (NNs.so imports exp from libm: glibc >= 2.28 e_exp.c, the -mfma variant -- csrc/libm_exp.h).  4096 of 4096 recorded outputs per
+ * network agree to the last bit (profiles/r04_accuracy.txt); sdpcut_nn_batch is the same kernel on a batch.
  */
 double neural_net_2D(const double X[5]);
 double neural_net_3D(const double X[9]);
