@@ -33,6 +33,7 @@
 #define LMIN_MAX_EVALS 8
 #endif
 
+
 // sqrt / reciprocal to ~2^-45 (hardware estimate 2^-23 + one Newton step): what a Laguerre step needs -- the step is a
 // correction, its error is multiplied by its own size
 __device__ __forceinline__ double lmin_sqrt_fast(double x)       // x > 0
@@ -139,6 +140,7 @@ template <int D>
 struct LminBlocksIn {
     double d[D], e2[D - 1], lam, tol;
     unsigned smask;      // bit i: the coupling between rows i and i + 1 is treated as zero
+    int max_it;
 };
 
 #ifndef SDPCUT_LMIN_BLOCKS_INLINE
@@ -157,7 +159,7 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
     double prev3 = 0.0;
     int prev_row = -1;
 #pragma unroll 1
-    for (int it = 0; it < LMIN_MAX_EVALS + 2 && !done && !bad; ++it) {
+    for (int it = 0; it < in.max_it && !done && !bad; ++it) {
         double pm2 = 0.0, pm1 = 1.0, dm2 = 0.0, dm1 = 0.0, sm2 = 0.0, sm1 = 0.0, nb = 0.0;
         double amin = 1e300;
         int row = -1;      // last row of the block whose step is the smallest
@@ -182,10 +184,12 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
             sm2 = sm1; sm1 = sp;
             nb += 1.0;
             const bool close = (i == D - 1) ? true : (((in.smask >> i) & 1u) != 0u);
-            const double ab = lmin_step(nb, nb - 1.0, p, dp, sp);
-            const bool take = close & (ab < amin);
-            amin = take ? ab : amin;
-            row = take ? i : row;
+            if (i == D - 1 || __any(close)) {      // (uniform over the lanes in here: a closing formula only where some lane closes a block)
+                const double ab = lmin_step(nb, nb - 1.0, p, dp, sp);
+                const bool take = close & (ab < amin);
+                amin = take ? ab : amin;
+                row = take ? i : row;
+            }
             pos = pos & ((p > 0.0) | close);       // leading minors inside a block
             fin = fin & ((p > 0.0) | !close);      // the blocks' own determinants
         }
@@ -291,7 +295,7 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
         for (int i = 0; i < D; ++i) in.d[i] = d[i];
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) in.e2[i] = e2[i];
-        in.lam = lam; in.tol = tol; in.smask = smask;
+        in.lam = lam; in.tol = tol; in.smask = smask; in.max_it = LMIN_MAX_EVALS + 2;
         lam = lmin_blocks_cold<D>(in);
         ok = lam == lam;
     }
