@@ -83,7 +83,8 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
 /* SDPCUT_OPT_ONE_LAUNCH (default 1): a list with several size classes is scored by ONE launch in which every class has its own
  * range of workgroups (the shipped networks; same scores bit for bit as a launch per class).  0, or a list the launch does not
  * cover (user networks that need the clamped path, the VALU / simple kernel variants): a launch per class, see the next option. */
-/* SDPCUT_OPT_SIDE_STREAMS (default 2): a list with several size classes may score its smaller classes on side streams of the handle,
+/* SDPCUT_OPT_SIDE_STREAMS (default 0 since r4 -- the default configuration picks no code path from a timing; only lists that
+ * SDPCUT_OPT_ONE_LAUNCH does not cover get here at all): a list with several size classes may score its smaller classes on side streams of the handle,
  * between a fork and a join event, next to the largest class on the handle's stream.  0: one launch after the other; 1: side
  * streams; 2: the first multi-class scoring of a candidate list measures both forms (~1 ms, once) and keeps the faster --
  * whether the streams run side by side depends on which hardware queues the process's streams were given. */

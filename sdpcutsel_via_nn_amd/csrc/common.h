@@ -76,7 +76,7 @@ struct sdpcut_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // the small size classes of a mixed cover are scored on side streams next to the largest one (launch_score)
     bool one_launch = true;      // SDPCUT_OPT_ONE_LAUNCH: the size classes of a mixed list in one launch (score_mfma_all_kernel)
-    int side_streams = 2;        // SDPCUT_OPT_SIDE_STREAMS: 0 off, 1 on, 2 measured once per candidate list (side_choice)
+    int side_streams = 0;        // SDPCUT_OPT_SIDE_STREAMS: 0 off (default since r4: no code path picked by a timing), 1 on, 2 measured once per candidate list (side_choice)
     int side_choice = -1;        // -1 not measured yet, 0 one after the other, 1 side streams
     float side_ms[2] = {0.f, 0.f};
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};

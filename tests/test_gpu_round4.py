@@ -201,3 +201,47 @@ def test_lambda_min_of_a_candidate_does_not_depend_on_its_neighbours():
         assert ref.shape[0] == N
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_lambda_min_on_points_outside_the_lp_box(oracle, k):
+    """csrc/lmin.h makes no use of 0 <= x, X <= 1: arbitrary symmetric lifted matrices (entries of either sign, graded over six
+    orders of magnitude, rank-one, all-equal, diagonal, zero) against LAPACK, relative to the norm of the matrix."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    n = 40
+    L = n * (n + 1) // 2
+    wl = synthetic.make_workload(nb_vars=n, k=k, count=30000, seed=100 + k)
+    si = wl["set_inds"][:, :k]
+    rng = np.random.default_rng(k)
+    iu = np.triu_indices(n)
+
+    def pack(X, x):
+        return np.concatenate([X[iu], x])
+    pts = []
+    X = rng.normal(size=(n, n)); X = 0.5 * (X + X.T)
+    pts.append(pack(X, rng.normal(size=n)))                                     # either sign, O(1)
+    g = 10.0 ** rng.uniform(-3, 3, size=n)
+    pts.append(pack(X * np.outer(g, g), rng.normal(size=n) * g))                # graded
+    v = rng.uniform(0, 1, size=n)
+    pts.append(pack(np.outer(v, v), v))                                         # rank one: lambda_min = 0 up to rounding
+    pts.append(pack(np.full((n, n), 0.3), np.full(n, 0.3)))                     # all equal
+    pts.append(pack(np.diag(rng.uniform(-1, 1, size=n)), np.zeros(n)))          # diagonal, x = 0: T is diagonal from the start
+    pts.append(np.zeros(L + n))                                                 # zero but for the corner 1
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(k)
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        for pi, vv in enumerate(pts):
+            sc.set_point(vv)
+            sc.score(_capi.EIG)
+            lam = sc.get_scores(obj=False)[0]
+            x, Xs = vv[L:][si], vv[:L][oracle.triu_positions(si, n)]
+            ref = oracle.eigmin_batch(k, x, Xs)
+            scale = 1.0 + np.abs(x).sum(axis=1) * 2 + np.abs(Xs).sum(axis=1) * 2
+            err = np.abs(lam - ref) / scale
+            assert np.isfinite(lam).all(), pi
+            assert err.max() <= 3e-15, (pi, float(err.max()))      # (two backward-stable solvers: a few ulp of the norm apart)
+    finally:
+        sc.close()
