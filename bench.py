@@ -210,6 +210,23 @@ def bench_c3(device_index, steps, warm=20):
         res["score_kernels_ms"] = float(np.mean(ms))
         res["candidates_per_s_dropin"] = n / (res["dropin_pair_ms"] * 1e-3)
         out["strategy_%d" % strat] = res
+    # (r4) the combined strategy at a GENERIC LP point as well (round 4 of the same trajectory): round 2 sits next to the McCormick
+    # vertex, where a quarter of the lifted matrices have a reducible tridiagonal form and ~5 % a nearly multiple lambda_min -- the
+    # worst case of csrc/lmin.h; rounds 4 and 5 are what a combined round costs once the cuts have moved the point
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rounds_%s_d%d_s4.npz" % (C3_INSTANCE.replace("-", "_"), C3_DIM)))
+    if int(g["r04_strat"]) == 4:
+        vv4, res4 = np.ascontiguousarray(g["r04_vars"], dtype=np.float64), {}
+        for name in ("fused_csr", "dropin_pair"):
+            for _ in range(warm):
+                cuts = fns[name](4, vv4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fns[name](4, vv4)
+            torch.cuda.synchronize()
+            res4[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
+            res4["cuts"] = cuts
+        out["strategy_4_round_4_generic_point"] = res4
     sc.close()
     return out
 

@@ -393,20 +393,22 @@ class Scorer(object):
         at all, valid until the next call on this Scorer; copy=True (default) detaches them."""
         ld = self.row_len
         self.round_count += 1
-        block, cap, n_out, n_total, new_strat = _c.c_void_p(), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
-        cnt = np.zeros(4, dtype=np.int64)
+        st = getattr(self, "_sr_out", None)
+        if st is None:      # the out-parameters of the call, made once per Scorer (a round is a few microseconds of host time)
+            block, cap, n_out, n_total, new_strat = _c.c_void_p(), _c.c_int64(0), _c.c_int64(0), _c.c_int64(0), _c.c_int32(0)
+            cnt = np.zeros(4, dtype=np.int64)
+            st = self._sr_out = (block, cap, n_out, n_total, new_strat, cnt,
+                                 (ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out), ctypes.byref(n_total), ctypes.byref(new_strat),
+                                  _ptr(cnt, _i64p)))
+        block, cap, n_out, n_total, new_strat, cnt, refs = st
         if point is not None:
             vv = _f64(point)
             n = self.nb_vars
             if vv.shape != (n * (n + 1) // 2 + n,):
                 raise ValueError("vars_values must be [X packed | x] of length n(n+1)/2 + n")
-            self._check(self._lib.sdpcut_round_view(
-                self._h, _ptr(vv, _dp), int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
-                ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+            self._check(self._lib.sdpcut_round_view(self._h, _ptr(vv, _dp), int(strat), int(sel_size), ld, *refs))
         else:
-            self._check(self._lib.sdpcut_select_round_view(
-                self._h, int(strat), int(sel_size), ld, ctypes.byref(block), ctypes.byref(cap), ctypes.byref(n_out),
-                ctypes.byref(n_total), ctypes.byref(new_strat), _ptr(cnt, _i64p)))
+            self._check(self._lib.sdpcut_select_round_view(self._h, int(strat), int(sel_size), ld, *refs))
         w, c = int(n_out.value), int(cap.value)
         if block.value and c:
             key = (block.value, c, ld)
