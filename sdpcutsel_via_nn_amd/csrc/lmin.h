@@ -246,7 +246,7 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
     const bool has_split = smask != 0u;
     // lanes with a split sit the hot loop out (done from the start) and go through the cold function behind it
     bool done = has_split, bad = false;
-    double prev3 = 0.0;
+    double prev3 = 0.0, prev_step = 0.0;
 #pragma unroll 1
     for (int it = 0; it < LMIN_MAX_EVALS; ++it) {
         if (!__any(!done & !bad)) break;
@@ -284,8 +284,13 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
         const double s2 = step * step;
         // the last step: below a quarter ulp of ||T||, or cubic convergence says the NEXT one would be (step^4 / previous^3 <= 1e-17)
         const bool conv = (step <= tol) | (s2 * s2 <= prev3);
+        // a lane whose FIFTH step is still more than a quarter of its fourth is converging linearly (a multiple or nearly multiple
+        // lambda_min shrinks the step by 0.27-0.37 per evaluation, a simple one by orders of magnitude by then: none of 1.2e6
+        // generic matrices trips this, tools/lmin_proto.py): it stops holding its wave and goes to Jacobi three evaluations earlier
+        bad = bad | ((it == 4) & !done & !conv & (step > 0.25 * prev_step));
         lam = done ? lam : lam + step;
         prev3 = 1e-17 * (s2 * step);
+        prev_step = step;
         done = done | conv;
     }
     ok = done & !bad;

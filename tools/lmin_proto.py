@@ -133,6 +133,8 @@ def lambda_min(A, stats=None):
     prev3 = np.zeros(B)
     nev = np.zeros(B, dtype=int)
     prev_row = np.full(B, -1)
+    prev_step = np.zeros(B)
+    slow = np.zeros(B, dtype=bool)
     for it in range(K_MAX + 2):
         pm2, pm1 = np.zeros(B), np.ones(B)
         dm2, dm1 = np.zeros(B), np.zeros(B)
@@ -159,6 +161,9 @@ def lambda_min(A, stats=None):
         step = amin
         s2 = step * step
         conv = (step <= tol) | ((row == prev_row) & (s2 * s2 <= prev3))      # (prediction: consecutive steps of ONE block)
+        if it == 4:      # a fifth step still above a quarter of the fourth: linear convergence, the device hands the lane to Jacobi here
+            slow |= (~has_split) & ~done & ~conv & (step > 0.25 * prev_step)
+        prev_step = np.where(done, prev_step, step)
         lam = np.where(done, lam, lam + step)
         prev3 = np.where(done, prev3, 1e-17 * s2 * step)
         prev_row = np.where(done, prev_row, row)
@@ -167,6 +172,7 @@ def lambda_min(A, stats=None):
         if it >= K_MAX - 1 and not (has_split & ~done).any():
             break
     done &= has_split | (nev <= K_MAX)
+    done &= ~slow
     if stats is not None:
         stats["evals"] = nev
         stats["notdone"] = int((~done).sum())
