@@ -88,15 +88,13 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * between a fork and a join event, next to the largest class on the handle's stream.  0: one launch after the other; 1: side
  * streams; 2: the first multi-class scoring of a candidate list measures both forms (~1 ms, once) and keeps the faster --
  * whether the streams run side by side depends on which hardware queues the process's streams were given. */
-/* SDPCUT_OPT_ONE_KERNEL_SELECT (default 1, r4): lists of at most 16 384 candidates with heads of at most 2 048 entries are selected and
- * ordered by ONE launch of one workgroup (keys in LDS, radix select, bitonic sort) instead of three or four; 0: A/B. */
 /* SDPCUT_OPT_STREAM_PRIORITY (default 0): 1 re-creates the handle's own stream with the device's highest priority.  For a handle
  * whose list is SHORT and whose rounds run next to another handle's (the QCQP round's objective cover beside its constraints
  * cover, sdpcut_round_csr_begin): its few small kernels are then dispatched ahead of the other list's waiting workgroups instead of
  * behind them.  Not allowed while a round is pending; ignored by a handle that runs on a caller's stream (sdpcut_set_stream). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
        SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6, SDPCUT_OPT_EIG_KERNEL = 7, SDPCUT_OPT_STREAM_PRIORITY = 8,
-       SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10, SDPCUT_OPT_ONE_KERNEL_SELECT = 11 };
+       SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10 };
 
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier

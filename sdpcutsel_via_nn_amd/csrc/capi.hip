@@ -2,7 +2,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -132,7 +131,6 @@ int sdpcut_create(int device_id, sdpcut_handle *out)
     }
     h->stream = h->own_stream;
     for (int i = 0; i < 4; ++i) hipEventCreate(&h->ev[i]);
-    if (const char *e = std::getenv("SDPCUT_ONE_KERNEL_SELECT")) h->one_kernel = std::atoi(e) != 0;      // A/B from tools (SDPCUT_OPT_ONE_KERNEL_SELECT)
     *out = h;
     return SDPCUT_OK;
 }
@@ -251,9 +249,6 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
         return SDPCUT_OK;
     case SDPCUT_OPT_ONE_LAUNCH:
         h->one_launch = value != 0;
-        return SDPCUT_OK;
-    case SDPCUT_OPT_ONE_KERNEL_SELECT:
-        h->one_kernel = value != 0;
         return SDPCUT_OK;
     case SDPCUT_OPT_SIDE_STREAMS:
         if (value < 0 || value > 2) return sdpcut_fail(h, SDPCUT_EINVAL, "SDPCUT_OPT_SIDE_STREAMS: 0 off, 1 on, 2 measured");

@@ -85,7 +85,6 @@ struct sdpcut_ctx {
     int kernel_variant = SDPCUT_KERNEL_MFMA;
     bool fuse_keys = true;         // SDPCUT_OPT_FUSE_KEYS (see include/sdpcut.h)
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
-    bool one_kernel = true;        // SDPCUT_OPT_ONE_KERNEL_SELECT (r4): lists <= 16384 with heads <= 2048 are selected by ONE launch (tk_one_kernel)
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     bool eig_kernel = true;        // SDPCUT_OPT_EIG_KERNEL: eigenvalue-only launches run eig_only_kernel (eig.hip)
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)

@@ -853,7 +853,6 @@ int64_t *topk_strong_counter(void *ws) { return ((TopkWs *)ws)->strong_rep; }
 bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k)
 {
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    if (h->one_kernel && h->N <= TK_ONE_N && k <= TK_ONE_K) return false;      // tk_one_kernel builds its own keys: nothing to count
     return h->fused_tail && !h->coop_launch && k >= 1 && k <= TK_MAXK && h->N > maxk;
 }
 
@@ -903,237 +902,6 @@ __global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t 
         ws->mode = mode;
         ws->counters[6] = mode;
         ws->counters[5] = strong_total(ws);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Short lists, the WHOLE selection in ONE launch (r4).  n <= TK_ONE_N candidates and a head of k <= TK_ONE_K
-// -- every QCQP cover of the paper's runs (3-variable sub-problems, a few hundred to 17 000 candidates, 5 %), the dim-5 covers of
-// the sparser BoxQP instances (spar070-050-1: 10 777, 10 %) -- used to go through three or four launches (tk_small / refine, tile
-// sort, merge ranks) whose ~5 us hand-offs and ~5 us of host time each were most of a 25 us job.  Here ONE workgroup of 1024
-// threads keeps all n keys in LDS (128 KB), runs the same MSD radix select over them (eight 8-bit digits at most, early stop as
-// soon as the keys above the threshold bin plus the bin fit the sort buffer), compacts the selected pairs in index order, sorts
-// them with a bitonic network in LDS by (key desc, [obj_improve desc,] index asc) and emits the head and the counters.
-// Same keys, same tie rules, same outputs as the multi-launch path (tests: every small list of the suites goes through here).
-// A tie group of the every-entry-visited regime that does not fit declares the selection void with flag 2 and leaves T / need in
-// state[8], exactly like resolve_digit: topk_tie_split answers.
-
-template <bool TIE>
-__device__ __forceinline__ void one_sort(uint64_t *sk, uint32_t *si, int P, const double *obj)
-{
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int t = threadIdx.x;
-            if (t < (P >> 1)) {
-                const int pos = 2 * t - (t & (stride - 1));
-                const int par = pos + stride;
-                const bool up = (pos & size) == 0;
-                const uint64_t ka = sk[pos], kb = sk[par];
-                const uint32_t ia = si[pos], ib = si[par];
-                if (comp_less<TIE>(kb, ib, ka, ia, obj) == up) {
-                    sk[pos] = kb; sk[par] = ka;
-                    si[pos] = ib; si[par] = ia;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__global__ __launch_bounds__(TK_ONE_THREADS) void tk_one_kernel(int mode, int64_t sel, int n, int k, int64_t base, double score_add,
-                                                                const double *eig, const double *obj, TopkWs *ws,
-                                                                int64_t *idx_out, double *score_out)
-{
-    __shared__ uint64_t keys[TK_ONE_N];
-    __shared__ uint64_t sk[TK_ONE_K];
-    __shared__ uint32_t si[TK_ONE_K];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t suf[256];
-    __shared__ uint32_t cnt[4];                  // class members, violated, positive, (unused)
-    __shared__ uint32_t wave_cnt[TK_ONE_THREADS / 64][2];
-    __shared__ uint64_t s_prefix;
-    __shared__ int s_need, s_stop, s_void;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const bool both = mode == TK_MODE_COMBAUTO;
-    mode = resolve_mode(mode, ws, sel);          // (the strong count was left by the score kernels of this round)
-    if (t < 4) cnt[t] = 0;
-    if (t == 0) { s_prefix = 0; s_stop = 0; s_void = 0; }
-    __syncthreads();
-    // ---- keys of all candidates into LDS; class size, violated, positive
-    {
-        uint32_t c_class = 0, c_viol = 0, c_pos = 0;
-        // (eight rounds of loads in flight per thread: one workgroup has nobody else to hide a memory round trip behind)
-        const double *pe = eig ? eig : obj, *po = obj ? obj : eig;      // a measure the mode does not use is never looked at
-        for (int i0 = 0; i0 < n; i0 += 8 * TK_ONE_THREADS) {
-            double e[8], o[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * TK_ONE_THREADS + t;
-                const int ic = i < n ? i : n - 1;
-                e[u] = pe[ic];
-                o[u] = po[ic];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * TK_ONE_THREADS + t;
-                if (i < n) {
-                    const double ev = eig ? e[u] : 0.0, ov = obj ? o[u] : 0.0;
-                    const uint64_t key = masked_key(mode, ev, ov);
-                    keys[i] = key;
-                    c_class += (mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? 1u : (key != 0ull);
-                    c_viol += (eig != nullptr) && (ev < SDPCUT_NEG_EIGVAL);
-                    c_pos += (obj != nullptr) && (ov > 0.0);
-                }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            c_class += __shfl_xor((int)c_class, off);
-            c_viol += __shfl_xor((int)c_viol, off);
-            c_pos += __shfl_xor((int)c_pos, off);
-        }
-        if (lane == 0) {
-            if (c_class) atomicAdd(&cnt[0], c_class);
-            if (c_viol) atomicAdd(&cnt[1], c_viol);
-            if (c_pos) atomicAdd(&cnt[2], c_pos);
-        }
-    }
-    __syncthreads();
-    const int cls = (int)cnt[0];
-    const int k_eff = k < cls ? k : cls;
-    if (t == 0) {
-        ws->counters[0] = cls;
-        ws->counters[1] = cnt[1];
-        ws->counters[2] = cnt[2];
-        ws->counters[3] = k_eff;
-        ws->counters[5] = strong_total(ws);
-        ws->counters[6] = mode;
-        ws->mode = mode;
-        ws->n_sel = k_eff;
-        s_need = k_eff;
-    }
-    __syncthreads();
-    if (k_eff == 0) return;
-    const bool comball = mode == TK_MODE_COMBALL;
-    // ---- MSD radix select over the keys in LDS: threshold key T (s_prefix) and how many of the keys equal to it are wanted
-    for (int p = 0; p < 8 && !s_stop; ++p) {
-        const int shift = 8 * (7 - p);
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        const uint64_t prefix = s_prefix;
-        for (int i0 = 0; i0 < n; i0 += TK_ONE_THREADS) {      // (every lane runs every round: hist_add is wave-cooperative)
-            const int i = i0 + t;
-            const uint64_t key = i < n ? keys[i] : 0ull;
-            const bool match = i < n && (p == 0 || ((key ^ prefix) >> (shift + 8)) == 0);
-            hist_add(hist, (uint32_t)((key >> shift) & 255), match);
-        }
-        __syncthreads();
-        if (t < 256) suf[t] = hist[t];
-        __syncthreads();
-        if (t < 256) {      // suffix sums over the 256 bins (four waves: shuffles, then the totals of the waves above)
-            uint32_t v = suf[t];
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_down((int)v, off);
-                if (lane + off < 64) v += o;
-            }
-            if (lane == 0) wave_cnt[wave][0] = v;
-            suf[t] = v;
-        }
-        __syncthreads();
-        if (t < 256) {
-            uint32_t v = suf[t];
-            for (int w = wave + 1; w < 4; ++w) v += wave_cnt[w][0];
-            suf[t] = v;
-        }
-        __syncthreads();
-        if (t < 256) {
-            const int need = s_need;
-            const int here = (int)suf[t], above = t < 255 ? (int)suf[t + 1] : 0;
-            if (here >= need && above < need) {      // exactly one bin
-                const uint64_t pre = prefix | ((uint64_t)t << shift);
-                const int in_bin = here - above;
-                const int superset = k_eff - (need - above) + in_bin;      // every key >= the bin's lowest value
-                if (p == 7 && comball && in_bin > need - above && superset > TK_ONE_K) {
-                    // more equal new scores at the threshold than the sort buffer holds, and their order is by obj_improve:
-                    // void, flag 2; T and the number still wanted from the group for topk_tie_split
-                    s_void = 1;
-                    ws->counters[4] = 2;
-                    ws->state[8].prefix = pre;
-                    ws->state[8].need = need - above;
-                    ws->state[8].stop = 0;
-                }
-                s_prefix = pre;
-                if ((p < 7 || comball) && superset <= TK_ONE_K) {
-                    s_need = in_bin;      // the whole bin goes into the sort, which puts the wanted k_eff first
-                    s_stop = 1;
-                } else {
-                    s_need = need - above;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (s_void) return;
-    const uint64_t T = s_prefix;
-    const int stop = s_stop, need = stop ? 0 : s_need;
-    // ---- compaction.  After an early stop every key >= T (T = the lowest value of the threshold bin) is taken, in any order: the
-    // sort orders them.  Otherwise every key above T and, of the keys equal to T, the `need` lowest indices -- in index order.
-    const bool all_members = mode == TK_MODE_OPT || mode == TK_MODE_COMBALL;
-    int greater = 0;
-    {
-        uint32_t g = 0;
-        for (int i = t; i < n; i += TK_ONE_THREADS) {
-            const uint64_t key = keys[i];
-            g += (stop ? key >= T : key > T) && (all_members || key != 0ull);
-        }
-        for (int off = 32; off > 0; off >>= 1) g += __shfl_xor((int)g, off);
-        if (lane == 0) wave_cnt[wave][0] = g;
-        __syncthreads();
-        for (int w = 0; w < TK_ONE_THREADS / 64; ++w) greater += (int)wave_cnt[w][0];
-        __syncthreads();
-    }
-    int base_gt = 0, base_eq = 0;
-    for (int i0 = 0; i0 < n; i0 += TK_ONE_THREADS) {
-        const int i = i0 + t;
-        const uint64_t key = i < n ? keys[i] : 0ull;
-        const bool member = i < n && (all_members || key != 0ull);
-        const bool is_gt = member && (stop ? key >= T : key > T);
-        const bool is_eq = member && !stop && key == T;
-        const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
-        if (lane == 0) { wave_cnt[wave][0] = (uint32_t)__popcll(mg); wave_cnt[wave][1] = (uint32_t)__popcll(me); }
-        __syncthreads();
-        int bg = base_gt, be = base_eq, tg = 0, te = 0;
-        for (int w = 0; w < TK_ONE_THREADS / 64; ++w) {
-            if (w < wave) { bg += (int)wave_cnt[w][0]; be += (int)wave_cnt[w][1]; }
-            tg += (int)wave_cnt[w][0];
-            te += (int)wave_cnt[w][1];
-        }
-        if (is_gt) {
-            const int slot = bg + __popcll(mg & ((1ull << lane) - 1ull));
-            sk[slot] = ~key;
-            si[slot] = (uint32_t)i;
-        }
-        if (is_eq) {
-            const int r = be + __popcll(me & ((1ull << lane) - 1ull));
-            if (r < need) {
-                sk[greater + r] = ~key;
-                si[greater + r] = (uint32_t)i;
-            }
-        }
-        base_gt += tg;
-        base_eq += te;
-        __syncthreads();
-    }
-    const int M = greater + (base_eq < need ? base_eq : need);      // compacted entries (>= k_eff after an early stop)
-    int P = 64;
-    while (P < M) P <<= 1;
-    for (int j = M + t; j < P; j += TK_ONE_THREADS) { sk[j] = ~0ull; si[j] = 0xffffffffu; }      // padding sorts last
-    __syncthreads();
-    if (comball) one_sort<true>(sk, si, P, obj);
-    else one_sort<false>(sk, si, P, obj);
-    const double add = (both && comball) ? 0.0 : score_add;      // (device-resolved regime: BIG_M belongs to the strong class only)
-    for (int r = t; r < k_eff; r += TK_ONE_THREADS) {
-        idx_out[r] = base + (int64_t)si[r];
-        score_out[r] = score_of(~sk[r]) + add;
     }
 }
 
@@ -1240,14 +1008,6 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    if (!digit_done && h->one_kernel && n <= TK_ONE_N && k <= TK_ONE_K && !h->shard_rec) {
-        // short list: the whole selection in one launch of one workgroup (tk_one_kernel)
-        hipLaunchKernelGGL(tk_one_kernel, dim3(1), dim3(TK_ONE_THREADS), 0, h->stream, mode, sel, (int)n, (int)k, h->base, score_add, eig, obj,
-                           ws, d_idx_out, d_score_out);
-        HIP_TRY(h, hipGetLastError());
-        if (d_counters_out) *d_counters_out = ws->counters;
-        return 0;
-    }
     const bool small = !digit_done && n <= maxk;
     if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
