@@ -282,6 +282,9 @@ struct RoundCsrArgs {
 };
 
 #define CSR_SPIN_LIMIT (1 << 22)
+#ifndef ROUND_MIN_BLOCKS
+#define ROUND_MIN_BLOCKS 8      // workgroups of an epilogue launch at least (they share the zeroing of the next round's top-k workspace)
+#endif
 
 __global__ __launch_bounds__(64) void round_csr_kernel(RoundCsrArgs R)
 {
@@ -438,7 +441,8 @@ int launch_round_rows(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, const int
     int zw = 0;
     int rc = topk_alt_ws(h, &zp, &zw);
     if (rc) return rc;
-    const int grid = (int)((cap + 63) / 64);
+    int grid = (int)((cap + 63) / 64);
+    if (grid < ROUND_MIN_BLOCKS) grid = ROUND_MIN_BLOCKS;      // (the workspace zeroing, see launch_round_csr)
     hipLaunchKernelGGL(round_rows_kernel, dim3(grid), dim3(64), 0, h->stream, cap, d_c4, d_idx, d_score, h->base, h->N,
                        h->d_set_orig, h->d_k, h->d_vars, h->nb_vars, h->L, coef_ld, (char *)block, hdr_bytes, zp, zw, done_serial,
                        h->d_done_ticket, (h->scored & SDPCUT_EIG) ? (const double *)h->d_eig : (const double *)nullptr);
@@ -474,8 +478,11 @@ int launch_round_csr(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, int64_t li
                      int ld, void *block, int64_t serial)
 {
     if (cap <= 0) return 0;
-    const int grid = (int)((cap + 63) / 64);
+    int grid = (int)((cap + 63) / 64);
     if (grid > 256) return sdpcut_fail(h, SDPCUT_EINVAL, "round_csr: head too long");
+    // (r4) the kernel also zeroes the next round's top-k workspace (124 KB): a head of a few entries is ONE workgroup, whose 64 lanes
+    // then spend ~20 us on 242 stores each -- most of the epilogue of a QCQP round with 7 cuts.  Workgroups beyond the head only zero.
+    if (grid < ROUND_MIN_BLOCKS) grid = ROUND_MIN_BLOCKS;
     if (!h->d_done_ticket) {
         // completion ticket (64 B) + the look-back words of the CSR epilogue (256 x 8 B)
         HIP_TRY(h, hipMalloc((void **)&h->d_done_ticket, 64 + 256 * 8));

@@ -860,7 +860,10 @@ bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k)
 // need no radix passes: ONE workgroup builds the keys, counts the class and compacts its members;
 // the sort that follows orders all of them and emits the first k_eff.  Three launches instead of
 // seven on the latency-bound end of the problem sizes.
-__global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t sel, int64_t n, int64_t k, const double *eig,
+#ifndef TK_SMALL_THREADS
+#define TK_SMALL_THREADS 1024     // (one workgroup: a row of the list per 1024 candidates instead of 256)
+#endif
+__global__ __launch_bounds__(TK_SMALL_THREADS) void tk_small_kernel(int mode, int64_t sel, int64_t n, int64_t k, const double *eig,
                                                               const double *obj, TopkWs *ws, uint64_t *sel_key,
                                                               uint32_t *sel_idx)
 {
@@ -869,10 +872,27 @@ __global__ __launch_bounds__(TK_THREADS) void tk_small_kernel(int mode, int64_t 
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int64_t i0 = 0; i0 < n; i0 += TK_THREADS) {
+    // (r4) eight rows of loads in flight: ONE workgroup has nobody to hide a memory round trip behind, and a 7899-candidate cover
+    // is 31 rows -- 23 us of dependent trips on the critical path of a QCQP round before, ~5 now
+    const double *pe = eig ? eig : obj, *po = obj ? obj : eig;      // (a measure the mode does not use is never looked at)
+    double pre_e[8], pre_o[8];
+    for (int64_t i0 = 0; i0 < n; i0 += TK_SMALL_THREADS) {
+        const int u = (int)((i0 / TK_SMALL_THREADS) & 7);
+        if (u == 0) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int64_t j = i0 + (int64_t)v * TK_SMALL_THREADS + threadIdx.x;
+                const int64_t jc = j < n ? j : n - 1;
+                pre_e[v] = pe[jc];
+                pre_o[v] = po[jc];
+            }
+        }
+        double e_u = pre_e[0], o_u = pre_o[0];
+#pragma unroll
+        for (int v = 1; v < 8; ++v) { e_u = (u == v) ? pre_e[v] : e_u; o_u = (u == v) ? pre_o[v] : o_u; }
         const int64_t i = i0 + threadIdx.x;
         const bool in = i < n;
-        const double e = (in && eig) ? eig[i] : 0.0, o = (in && obj) ? obj[i] : 0.0;
+        const double e = (in && eig) ? e_u : 0.0, o = (in && obj) ? o_u : 0.0;
         const uint64_t key = in ? masked_key(mode, e, o) : 0ull;
         const bool member = in && ((mode == TK_MODE_OPT || mode == TK_MODE_COMBALL) ? true : key != 0ull);
         const unsigned long long mm = __ballot(member);
@@ -1010,7 +1030,7 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
     const bool small = !digit_done && n <= maxk;
     if (small) {
-        hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
+        hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_SMALL_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
     } else if (!digit_done) {
         hipLaunchKernelGGL(tk_keys_kernel, dim3(grid), dim3(TK_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, h->d_key_a, ws);
