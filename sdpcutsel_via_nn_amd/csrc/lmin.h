@@ -18,10 +18,13 @@
 //     1.2-2.0e-15 on the bench lists, against 1.3-2.0e-15 of LAPACK's own QL run on the same T).
 //     A step is "the last one" when the NEXT step of a cubically convergent sequence, step^4 / previous^3, is below
 //     1e-17, or when it is below a quarter ulp of ||T||: 3.3-3.7 evaluations per matrix, 4.8-5.2 per wave of 64.
-//  4. A multiple or nearly multiple lambda_min (exactly reducible T with equal eigenvalues in two blocks: a few per cent
-//     of the candidates at the McCormick vertex x = 0.5, X in {0, 0.5}, none at generic LP points) makes the convergence
-//     linear.  Such a lane gives up after LMIN_MAX_EVALS evaluations (ok = false) and the caller runs Jacobi on it --
-//     per lane: a candidate's lambda_min depends on its matrix alone, never on its neighbours in the wave.
+//  4. A multiple lambda_min makes the convergence linear.  At structured LP vertices (x = 0.5, X in {0, 0.5}: a quarter of the
+//     candidates of rounds 1-3, none at generic LP points) T is numerically REDUCIBLE there -- couplings at rounding level --
+//     and is iterated block by block (lmin_blocks_cold): every block has simple eigenvalues.  A coupling counts as zero by
+//     LAPACK's relative deflation rule or when it is below the stopping tolerance itself (the exactly singular matrices, whose
+//     trailing d_i and e_i are all rounding noise).  What is left -- a NEARLY multiple lambda_min with couplings above both
+//     thresholds, < 0.1 % of the candidates of a structured round -- gives up after five evaluations (ok = false) and the
+//     caller runs Jacobi on it -- per lane: a candidate's lambda_min depends on its matrix alone, never on its neighbours.
 //
 // ~100 (Householder) + ~30 (bound) + ~45 per evaluation: ~340 instructions per 4x4 matrix, ~620 per 6x6.
 #pragma once
@@ -31,6 +34,9 @@
 
 #ifndef LMIN_MAX_EVALS
 #define LMIN_MAX_EVALS 8
+#endif
+#ifndef SDPCUT_LMIN_ABS_SPLIT
+#define SDPCUT_LMIN_ABS_SPLIT 1.0      // absolute deflation threshold in units of the stopping tolerance (0: relative rule only)
 #endif
 
 
@@ -240,9 +246,14 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
     // (c = 4 here, 1 there): what the reflections leave of an exact zero between rows with O(1) diagonals goes; a coupling of
     // 1e-15 between rows whose diagonals are themselves ~1e-15 -- the LP noise around an exactly singular block, which decides
     // on which side of -1e-15 lambda_min falls (cut_select_qp.py:24, :647) -- stays, and such a lane ends with Jacobi as before.
+    // (r4, late) ... or e_i^2 <= (SDPCUT_LMIN_ABS_SPLIT tol)^2: a coupling below the stopping tolerance moves no eigenvalue by more than the
+    // stopping rule already allows.  That is the exactly singular matrix of a structured vertex, whose trailing d_i, e_i are ALL at
+    // rounding level -- the relative rule has nothing to compare with there, and the two- or threefold zero eigenvalue made these
+    // lanes (5 % of the candidates, 70 % of the WAVES of round 2 of spar125-075-1) converge linearly and end in Jacobi.
     unsigned smask = 0;
+    const double abs2 = (SDPCUT_LMIN_ABS_SPLIT * SDPCUT_LMIN_ABS_SPLIT) * (tol * tol);
 #pragma unroll
-    for (int i = 0; i < D - 1; ++i) smask |= (e2[i] <= 1.9721522630525295e-31 * fabs(d[i] * d[i + 1])) ? (1u << i) : 0u;
+    for (int i = 0; i < D - 1; ++i) smask |= (e2[i] <= fmax(1.9721522630525295e-31 * fabs(d[i] * d[i + 1]), abs2)) ? (1u << i) : 0u;
     const bool has_split = smask != 0u;
     // lanes with a split sit the hot loop out (done from the start) and go through the cold function behind it
     bool done = has_split, bad = false;

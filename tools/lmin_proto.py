@@ -107,7 +107,8 @@ def poly(d, e2, lam):
 
 
 K_MAX = int(os.environ.get("K_MAX", "8"))       # evaluations a lane gets; lanes that have not converged by then are left to Jacobi
-SPLIT = os.environ.get("SPLIT", "1") == "1"     # treat couplings below 2 ulp of ||T|| as zero: lambda_min = min over the blocks
+SPLIT = os.environ.get("SPLIT", "1") == "1"     # deflate negligible couplings: lambda_min = min over the blocks
+ABS_SPLIT = float(os.environ.get("ABS_SPLIT", "1"))   # absolute deflation threshold in units of the stopping tolerance (0 = relative rule only)
 
 
 def lag_step(nb, p, dp, sp):
@@ -127,6 +128,10 @@ def lambda_min(A, stats=None):
     tol = 0.25 * EPS * scale
     # LAPACK's relative deflation criterion (dsterf: e^2 <= eps^2 |d_i d_{i+1}|), with 4 eps
     split = (e2 <= (4 * 0.5 * EPS) ** 2 * np.abs(d[:, :-1] * d[:, 1:])) if SPLIT else np.zeros_like(e2, dtype=bool)
+    if SPLIT and ABS_SPLIT > 0:
+        # ... or below the stopping tolerance itself (|e| <= tol moves no eigenvalue by more than tol): the exactly singular matrices
+        # of structured vertices, whose trailing d_i, e_i are ALL at rounding level, where the relative rule has nothing to compare with
+        split |= e2 <= ((ABS_SPLIT * tol) ** 2)[:, None]
     has_split = split.any(axis=1)
     e2s = np.where(split, 0.0, e2)
     done = np.zeros(B, dtype=bool)
