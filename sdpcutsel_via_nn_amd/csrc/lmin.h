@@ -22,9 +22,12 @@
 //     candidates of rounds 1-3, none at generic LP points) T is numerically REDUCIBLE there -- couplings at rounding level --
 //     and is iterated block by block (lmin_blocks_cold): every block has simple eigenvalues.  A coupling counts as zero by
 //     LAPACK's relative deflation rule or when it is below the stopping tolerance itself (the exactly singular matrices, whose
-//     trailing d_i and e_i are all rounding noise).  What is left -- a NEARLY multiple lambda_min with couplings above both
-//     thresholds, < 0.1 % of the candidates of a structured round -- gives up after five evaluations (ok = false) and the
-//     caller runs Jacobi on it -- per lane: a candidate's lambda_min depends on its matrix alone, never on its neighbours.
+//     trailing d_i and e_i are all rounding noise).  What is left is a NEARLY multiple lambda_min with couplings above both
+//     thresholds: LP noise of 1e-15 inside a singular block, which couples two zero eigenvalues at the very level that decides
+//     on which side of -1e-15 lambda_min falls (round 2 of a run: 0.03 % of the 4-variable candidates of spar125-075-1, a
+//     quarter of the 3-variable ones of spar125-075-2; none from round 4 on).  Such a lane gives up after five evaluations
+//     (ok = false) and the caller runs Jacobi on it -- per lane: a candidate's lambda_min depends on its matrix alone, never
+//     on its neighbours in the wave.
 //
 // ~100 (Householder) + ~30 (bound) + ~45 per evaluation: ~340 instructions per 4x4 matrix, ~620 per 6x6.
 #pragma once
@@ -145,7 +148,8 @@ __device__ __forceinline__ void lmin_tridiagonalise(double (&a)[D][D], double (&
 template <int D>
 struct LminBlocksIn {
     double d[D], e2[D - 1], lam, tol;
-    unsigned smask;      // bit i: the coupling between rows i and i + 1 is treated as zero
+    double abs2;         // couplings with e_i^2 <= abs2 are splits as well (the absolute rule, see lmin_laguerre)
+    unsigned smask;      // bit i: the coupling between rows i and i + 1 is treated as zero (the relative rule)
     int max_it;
 };
 
@@ -161,7 +165,10 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
 {
 #pragma clang fp contract(off)
     double lam = in.lam;
-    bool done = false, bad = false;
+    unsigned smask = in.smask;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) smask |= (in.e2[i] <= in.abs2) ? (1u << i) : 0u;
+    bool done = false, bad = smask == 0u;      // (a lane that gave up in the hot loop and has no split by either rule: Jacobi)
     double prev3 = 0.0;
     int prev_row = -1;
 #pragma unroll 1
@@ -174,7 +181,7 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
         for (int i = 0; i < D; ++i) {
             double c = 0.0;
             if (i > 0) {
-                const bool s = ((in.smask >> (i - 1)) & 1u) != 0u;
+                const bool s = ((smask >> (i - 1)) & 1u) != 0u;
                 pm1 = s ? 1.0 : pm1;
                 dm1 = s ? 0.0 : dm1;
                 sm1 = s ? 0.0 : sm1;
@@ -189,7 +196,7 @@ __device__ __attribute__((noinline)) double lmin_blocks_cold(LminBlocksIn<D> in)
             dm2 = dm1; dm1 = dp;
             sm2 = sm1; sm1 = sp;
             nb += 1.0;
-            const bool close = (i == D - 1) ? true : (((in.smask >> i) & 1u) != 0u);
+            const bool close = (i == D - 1) ? true : (((smask >> i) & 1u) != 0u);
             if (i == D - 1 || __any(close)) {      // (uniform over the lanes in here: a closing formula only where some lane closes a block)
                 const double ab = lmin_step(nb, nb - 1.0, p, dp, sp);
                 const bool take = close & (ab < amin);
@@ -246,14 +253,9 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
     // (c = 4 here, 1 there): what the reflections leave of an exact zero between rows with O(1) diagonals goes; a coupling of
     // 1e-15 between rows whose diagonals are themselves ~1e-15 -- the LP noise around an exactly singular block, which decides
     // on which side of -1e-15 lambda_min falls (cut_select_qp.py:24, :647) -- stays, and such a lane ends with Jacobi as before.
-    // (r4, late) ... or e_i^2 <= (SDPCUT_LMIN_ABS_SPLIT tol)^2: a coupling below the stopping tolerance moves no eigenvalue by more than the
-    // stopping rule already allows.  That is the exactly singular matrix of a structured vertex, whose trailing d_i, e_i are ALL at
-    // rounding level -- the relative rule has nothing to compare with there, and the two- or threefold zero eigenvalue made these
-    // lanes (5 % of the candidates, 70 % of the WAVES of round 2 of spar125-075-1) converge linearly and end in Jacobi.
     unsigned smask = 0;
-    const double abs2 = (SDPCUT_LMIN_ABS_SPLIT * SDPCUT_LMIN_ABS_SPLIT) * (tol * tol);
 #pragma unroll
-    for (int i = 0; i < D - 1; ++i) smask |= (e2[i] <= fmax(1.9721522630525295e-31 * fabs(d[i] * d[i + 1]), abs2)) ? (1u << i) : 0u;
+    for (int i = 0; i < D - 1; ++i) smask |= (e2[i] <= 1.9721522630525295e-31 * fabs(d[i] * d[i + 1])) ? (1u << i) : 0u;
     const bool has_split = smask != 0u;
     // lanes with a split sit the hot loop out (done from the start) and go through the cold function behind it
     bool done = has_split, bad = false;
@@ -299,19 +301,27 @@ __device__ __forceinline__ double lmin_laguerre(double (&a)[D][D], bool &ok)
         // lambda_min shrinks the step by 0.27-0.37 per evaluation, a simple one by orders of magnitude by then: none of 1.2e6
         // generic matrices trips this, tools/lmin_proto.py): it stops holding its wave and goes to Jacobi three evaluations earlier
         bad = bad | ((it == 4) & !done & !conv & (step > 0.25 * prev_step));
-        lam = done ? lam : lam + step;
+        lam = (done | bad) ? lam : lam + step;      // (a lane that gave up stands still: what it hands on must not depend on how long its wave goes on)
         prev3 = 1e-17 * (s2 * step);
         prev_step = step;
         done = done | conv;
     }
     ok = done & !bad;
-    if (has_split) {      // (skipped by the whole wave when nobody needs it)
+    // (r4, late) A lane that gave up gets a second deflation rule before it goes to Jacobi, and so do the lanes of the block
+    // iteration: e_i^2 <= (SDPCUT_LMIN_ABS_SPLIT tol)^2 -- a coupling below the stopping tolerance moves no eigenvalue by more than
+    // the stopping rule already allows.  That is the exactly singular matrix of a structured vertex, whose trailing d_i, e_i are ALL
+    // at rounding level: the relative rule has nothing to compare with there, and the two- or threefold zero eigenvalue made these
+    // lanes (5 % of the candidates, 70 % of the WAVES of round 2 of spar125-075-1) converge linearly and end in Jacobi.  Asked
+    // inside the cold function: the rule costs the hot path nothing.  The iterate a lane that gave up hands over is still a lower
+    // bound of its spectrum (and if it is not -- never observed -- the block iteration notices and returns NaN).
+    if (!ok || has_split) {      // (skipped by the whole wave when nobody needs it)
         LminBlocksIn<D> in;
 #pragma unroll
         for (int i = 0; i < D; ++i) in.d[i] = d[i];
 #pragma unroll
         for (int i = 0; i < D - 1; ++i) in.e2[i] = e2[i];
         in.lam = lam; in.tol = tol; in.smask = smask; in.max_it = LMIN_MAX_EVALS + 2;
+        in.abs2 = (SDPCUT_LMIN_ABS_SPLIT * SDPCUT_LMIN_ABS_SPLIT) * (tol * tol);
         lam = lmin_blocks_cold<D>(in);
         ok = lam == lam;
     }

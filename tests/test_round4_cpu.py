@@ -133,6 +133,37 @@ def test_lambda_min_solver_at_structured_vertices(oracle, golden_boxqp):
             assert st["split"] > 0
 
 
+def test_lambda_min_solver_on_exactly_singular_matrices(oracle):
+    """Rounds 1 and 3 of a BoxQP run (spar125-075-2, dim 3, recorded trajectory): a per cent of the lifted matrices are exactly
+    singular with a two- or threefold zero eigenvalue, and the trailing d_i, e_i of their tridiagonal forms are ALL rounding noise --
+    LAPACK's relative deflation rule has nothing to compare with, the absolute one (a coupling below the stopping tolerance,
+    csrc/lmin.h SDPCUT_LMIN_ABS_SPLIT) splits them: almost nobody is left to Jacobi, same accuracy, same side of -1e-15 as LAPACK
+    for everybody the solver answers.  (Round 2 keeps its Jacobi lanes: LP noise of 1e-15 INSIDE a singular block couples two zero
+    eigenvalues at the very level that decides the classification -- not deflated by either rule.)"""
+    P = _proto()
+    from sdpcutsel_via_nn_amd import _capi, harness
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rounds_spar125_075_2_d3_s4.npz"))
+    inst = harness.parse_boxqp(os.path.join(ROOT, "tests", "golden", "instances", "spar125-075-2.in"))
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    S, ks, N = _capi.enumerate_cover(inst["adj"], 3)
+    m = np.nonzero(ks == 3)[0]
+    for r in (1, 3):
+        vv = g["r%02d_vars" % r]
+        A = P.lifted(vv[L:][S[m, :3]], vv[:L][oracle.triu_positions(S[m, :3], n)], 3)
+        ref = np.linalg.eigvalsh(A, UPLO="U")[:, 0]
+        left = {}
+        for abs_split in (0.0, 1.0):
+            P.ABS_SPLIT = abs_split
+            try:
+                lam, ok = P.lambda_min(A)
+            finally:
+                P.ABS_SPLIT = 1.0
+            left[abs_split] = int((~ok).sum())
+            assert np.abs(lam - ref)[ok].max() <= 3e-15
+            assert np.array_equal((lam < -1e-15)[ok], (ref < -1e-15)[ok])
+        assert left[0.0] >= 1000 and left[1.0] <= 20, (r, left)
+
+
 def test_exact_eigenvalue_tool_on_a_known_matrix():
     """tools/lmin_truth.py (rational characteristic polynomial + 80-digit Newton): the noise-floor evidence rests on it"""
     tools = os.path.join(ROOT, "tools")

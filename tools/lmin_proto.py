@@ -117,30 +117,21 @@ def lag_step(nb, p, dp, sp):
     return np.where((p > 0) & (den > 0), nb * p / np.where(den > 0, den, 1.0), 0.0)
 
 
-def lambda_min(A, stats=None):
-    """-> (lam, ok): ok False = not converged within K_MAX evaluations (a nearly multiple lambda_min: linear convergence).
-    An exactly reducible T (couplings at rounding level: the structured LP vertices) is handled block by block: every block has
-    simple eigenvalues, the step is the smallest of the blocks' Laguerre steps -- a lower bound of the distance to the smallest
-    eigenvalue of ANY block, cubically convergent for the block that attains it, indifferent to two blocks sharing it."""
-    d, e2, ea = tridiagonalise(A)
+def _iterate(d, e2, split, lam, tol, max_it, give_up_early):
+    """Laguerre from the left, block by block where `split` says so (a lane without a split is one block).  Returns (lam, done,
+    evaluations); give_up_early: the hot loop's rule (a fifth step still above a quarter of the fourth: linear convergence)."""
     B, n = d.shape
-    lam, scale = lower_bound(d, e2, ea)
-    tol = 0.25 * EPS * scale
-    # LAPACK's relative deflation criterion (dsterf: e^2 <= eps^2 |d_i d_{i+1}|), with 4 eps
-    split = (e2 <= (4 * 0.5 * EPS) ** 2 * np.abs(d[:, :-1] * d[:, 1:])) if SPLIT else np.zeros_like(e2, dtype=bool)
-    if SPLIT and ABS_SPLIT > 0:
-        # ... or below the stopping tolerance itself (|e| <= tol moves no eigenvalue by more than tol): the exactly singular matrices
-        # of structured vertices, whose trailing d_i, e_i are ALL at rounding level, where the relative rule has nothing to compare with
-        split |= e2 <= ((ABS_SPLIT * tol) ** 2)[:, None]
-    has_split = split.any(axis=1)
     e2s = np.where(split, 0.0, e2)
     done = np.zeros(B, dtype=bool)
+    slow = np.zeros(B, dtype=bool)
     prev3 = np.zeros(B)
     nev = np.zeros(B, dtype=int)
     prev_row = np.full(B, -1)
     prev_step = np.zeros(B)
-    slow = np.zeros(B, dtype=bool)
-    for it in range(K_MAX + 2):
+    lam = lam.copy()
+    for it in range(max_it):
+        if (done | slow).all():
+            break
         pm2, pm1 = np.zeros(B), np.ones(B)
         dm2, dm1 = np.zeros(B), np.zeros(B)
         sm2, sm1 = np.zeros(B), np.zeros(B)
@@ -162,22 +153,54 @@ def lambda_min(A, stats=None):
             ab = lag_step(nb, p, dp, sp)
             take = close & (ab < amin)
             amin, row = np.where(take, ab, amin), np.where(take, i, row)
-        nev[~done] += 1
+        act = ~done & ~slow
+        nev[act] += 1
         step = amin
         s2 = step * step
         conv = (step <= tol) | ((row == prev_row) & (s2 * s2 <= prev3))      # (prediction: consecutive steps of ONE block)
-        if it == 4:      # a fifth step still above a quarter of the fourth: linear convergence, the device hands the lane to Jacobi here
-            slow |= (~has_split) & ~done & ~conv & (step > 0.25 * prev_step)
-        prev_step = np.where(done, prev_step, step)
-        lam = np.where(done, lam, lam + step)
-        prev3 = np.where(done, prev3, 1e-17 * s2 * step)
-        prev_row = np.where(done, prev_row, row)
-        done |= conv
-        # lanes without a split have K_MAX evaluations (the device's hot loop), lanes with one K_MAX + 2 (its block loop)
-        if it >= K_MAX - 1 and not (has_split & ~done).any():
-            break
-    done &= has_split | (nev <= K_MAX)
-    done &= ~slow
+        if give_up_early and it == 4:
+            slow |= act & ~conv & (step > 0.25 * prev_step)
+        prev_step = np.where(act, step, prev_step)
+        lam = np.where(act & ~slow, lam + step, lam)
+        prev3 = np.where(act, 1e-17 * s2 * step, prev3)
+        prev_row = np.where(act, row, prev_row)
+        done |= act & conv & ~slow
+    return lam, done, nev
+
+
+def lambda_min(A, stats=None):
+    """-> (lam, ok): ok False = left to Jacobi (a NEARLY multiple lambda_min: linear convergence).
+    A reducible T (couplings at rounding level: the structured LP vertices) is handled block by block: every block has simple
+    eigenvalues, the step is the smallest of the blocks' Laguerre steps -- a lower bound of the distance to the smallest eigenvalue
+    of ANY block, cubically convergent for the block that attains it, indifferent to two blocks sharing it.  As on the device:
+    lanes split by LAPACK's relative rule go through the block loop (K_MAX + 2 evaluations), the others through the hot loop
+    (K_MAX, early give-up); for a lane that gave up there, and for the lanes of the block loop, a coupling below ABS_SPLIT tol is a split as
+    well (the former go through the block loop too, from the iterate they reached)."""
+    d, e2, ea = tridiagonalise(A)
+    B, n = d.shape
+    lam0, scale = lower_bound(d, e2, ea)
+    tol = 0.25 * EPS * scale
+    # LAPACK's relative deflation criterion (dsterf: e^2 <= eps^2 |d_i d_{i+1}|), with 4 eps
+    split = (e2 <= (4 * 0.5 * EPS) ** 2 * np.abs(d[:, :-1] * d[:, 1:])) if SPLIT else np.zeros_like(e2, dtype=bool)
+    has_split = split.any(axis=1)
+    nosplit = np.zeros_like(split)
+    lam = lam0.copy()
+    done = np.zeros(B, dtype=bool)
+    nev = np.zeros(B, dtype=int)
+    h = ~has_split
+    if h.any():
+        lam[h], done[h], nev[h] = _iterate(d[h], e2[h], nosplit[h], lam0[h], tol[h], K_MAX, True)
+    cold = has_split.copy()
+    if SPLIT and ABS_SPLIT > 0:
+        # ... or, for a lane that gave up, below the stopping tolerance itself (|e| <= tol moves no eigenvalue by more than tol): the
+        # exactly singular matrices of structured vertices, whose trailing d_i, e_i are ALL at rounding level
+        extra = (e2 <= ((ABS_SPLIT * tol) ** 2)[:, None]) & ((h & ~done) | has_split)[:, None]
+        split = split | extra
+        cold |= extra.any(axis=1)
+    if cold.any():
+        l2, d2, n2 = _iterate(d[cold], e2[cold], split[cold], lam[cold], tol[cold], K_MAX + 2, False)
+        lam[cold], done[cold] = l2, d2
+        nev[cold] += n2
     if stats is not None:
         stats["evals"] = nev
         stats["notdone"] = int((~done).sum())
