@@ -143,6 +143,9 @@ __device__ __forceinline__ double exp_y8_scaled(double y8_in, double y8max)     
 // into the exponent field of p^4 with one integer add -- p^4 lies in [0.65, 1.47] and |k| <= 117, so the field
 // neither overflows nor reaches the denormals -- and the last squaring, the scaling and the addend become ONE
 // fma: 14 instead of 16 issue slots per activation, one rounding less.
+#ifndef SDPCUT_EXP_SCALE_LDEXP
+#define SDPCUT_EXP_SCALE_LDEXP 1
+#endif
 template <int SHIFT>
 __device__ __forceinline__ double exp_y8_plus_bounded(double y8, double addend)
 {
@@ -160,7 +163,14 @@ __device__ __forceinline__ double exp_y8_plus_bounded(double y8, double addend)
     p = fma(p, r, 1.0);
     p = p * p;
     p = p * p;                                                       // exp(r)^4
+#if SDPCUT_EXP_SCALE_LDEXP
+    // (r4) v_ldexp_f64 with the low dword of t as its integer operand: ONE instruction for the scaled copy where the integer add
+    // into the exponent field needs two (v_lshl_add_u32 on the high dword + a v_mov_b32 of the low one to complete the register
+    // pair -- the unscaled p is still needed).  Same bits: both are exact scalings by 2^(k - SHIFT) in this range.
+    const double ps = ldexp(p, __double2loint(t));
+#else
     const double ps = __hiloint2double(__double2hiint(p) + (__double2loint(t) << 20), __double2loint(p));
+#endif
     return fma(ps, p, addend);
 }
 __device__ __forceinline__ double exp_y8(double y8_in, double y8max)     // exp(8 y8_in), y8_in = -n / 4
