@@ -167,7 +167,7 @@ int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap,
     int rc;
     const int fast_mode = (h->scored & need) == 0 ? rank_fast_mode(h, strat, sel_size, cap, nullptr) : 0;
     const bool want_auto = allow_auto && strat == SDPCUT_STRAT_COMB;
-    const bool count_digit = h->fuse_keys && topk_fuse_ok(h, cap);
+    const bool count_digit = h->fuse_keys && topk_fuse_ok(h, cap, strat == SDPCUT_STRAT_COMB);
     if (fast_mode && (want_auto || count_digit)) {
         void *ws = nullptr;
         rc = topk_begin(h, &ws, nullptr);

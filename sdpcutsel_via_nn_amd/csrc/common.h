@@ -244,7 +244,7 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
 // with the key array: what a score launch needs to run the selection's first pass itself
 // (ScoreFuse); follow with topk_select_enqueue(..., stage = 3)
 int topk_begin(sdpcut_ctx *h, void **ws, uint64_t **keys);
-bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k);     // may a score launch take a ScoreFuse for a head of k entries?
+bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k, bool comb);     // may a score launch take a ScoreFuse for a head of k entries?
 int64_t *topk_strong_counter(void *ws);      // TopkWs::strong_rep (TK_SREP = 8 replicas) of a workspace handed out by topk_begin
 int topk_select_on_device(sdpcut_ctx *h, int mode, int64_t k, double score_add, int64_t *d_idx_out,
                           double *d_score_out, int64_t cnt[5]);

@@ -850,9 +850,20 @@ int64_t *topk_strong_counter(void *ws) { return ((TopkWs *)ws)->strong_rep; }
 
 // may the score kernels count the leading digit for a head of k entries (ScoreFuse, stage 3)?  Lists
 // that fit the sort buffers whole skip the radix passes altogether (tk_small_kernel).
-bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k)
+// Which lists the one-workgroup selection takes (measured, profiles/r04_short_list_selection.txt: fused rounds on lists of 64 ..
+// 65 536 candidates, both paths alternating on one box).  Below ~3000 candidates sorting every class member costs less than
+// selecting first (two tiles at most); above 8192 the multi-workgroup passes win again -- except in the combined strategy, whose
+// tie-aware sort of a whole class is dearer: there 2048 .. 12 288.
+static bool smallsel_range(int64_t n, int64_t k, bool comb)
+{
+    if (!TK_SMALLSEL || k > TK_LDSK || n > TK_SMALLSEL_N) return false;
+    return comb ? (n > 2048 && n <= 12288) : (n > 3072 && n <= 8192);
+}
+
+bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k, bool comb)
 {
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
+    if (smallsel_range(h->N, k, comb)) return false;      // tk_smallsel_kernel builds its own keys: nothing to count
     return h->fused_tail && !h->coop_launch && k >= 1 && k <= TK_MAXK && h->N > maxk;
 }
 
@@ -923,6 +934,347 @@ __global__ __launch_bounds__(TK_SMALL_THREADS) void tk_small_kernel(int mode, in
         ws->counters[6] = mode;
         ws->counters[5] = strong_total(ws);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Short lists WITH a selection (r4, late).  tk_small_kernel hands EVERY class member to the sort: fine for a few hundred
+// candidates, but a cover of 8192 with a head of 409 was sorted whole -- 16 tiles, and a merge in which every entry searches
+// fifteen other tiles: tile sort 14.5 + merge 31 us of a 100 us round (a 1024-candidate list: 13 + 5.4) -- and lists of
+// 8193 .. 16384 went through tk_refine_kernel with four workgroups (27 us of flag waits).  Here ONE workgroup of 1024 threads
+// keeps the keys of n <= TK_SMALLSEL_N candidates in LDS, runs the MSD radix select over them -- the leading bytes all class
+// members share are skipped, a pass is sixteen LDS rows at most -- and stops as soon as the keys above the threshold bin plus the
+// bin fit the tiles the head needs anyway (a multiple of TK_TILE): that superset goes to the sort.  Same keys, same tie rules,
+// same counters as the other paths: a tie group cut at the last digit is cut by index (lowest first); in the every-entry-visited
+// regime, whose ties go by obj_improve, the whole group is taken, or -- if it does not fit the merge's LDS -- the selection is
+// declared void with flag 2 and T / need left in state[8] for topk_tie_split, exactly like resolve_digit.
+// one digit resolved by ONE wave (lanes own four bins each): suffix sums over the 256 bins, the bin that holds the need-th largest
+// key, the early-stop decision.  hist is cleared for the next pass on the way.  (Called by wave 0 between two workgroup barriers.)
+struct SmallSelState {
+    uint64_t prefix;
+    int need, stop, is_void, in_bin;
+};
+__device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *st, int p, int k_eff, int cap, bool comball, TopkWs *ws)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = hist[4 * lane + j]; hist[4 * lane + j] = 0; }
+    const uint32_t mine = h[0] + h[1] + h[2] + h[3];
+    uint32_t v = mine;                       // inclusive suffix sum over the lanes
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_down((int)v, off);
+        if (lane + off < 64) v += o;
+    }
+    const int need = st->need;
+    const uint64_t prefix = st->prefix;
+    const int shift = 8 * (7 - p);
+    int above = (int)(v - mine);             // keys in the bins above this lane's four
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        const int here = above + (int)h[j];
+        if (here >= need && above < need) {      // exactly one bin of one lane
+            const int bin = 4 * lane + j;
+            const uint64_t pre = prefix | ((uint64_t)bin << shift);
+            const int in_bin = (int)h[j];
+            const int superset = k_eff - (need - above) + in_bin;      // every key >= the bin's lowest value
+            const bool whole_group = p == 7 && comball && in_bin > need - above;      // a tie group that is ordered by obj_improve
+            if (whole_group && superset > TK_LDSK) {
+                // more equal new scores at the threshold than the merge holds: void, flag 2; T and the number still wanted from
+                // the group for topk_tie_split
+                st->is_void = 1;
+                ws->counters[4] = 2;
+                ws->state[8].prefix = pre;
+                ws->state[8].need = need - above;
+                ws->state[8].stop = 0;
+            }
+            st->prefix = pre;
+            st->in_bin = in_bin;
+            if ((p < 7 && superset <= cap) || (p == 7 && comball && superset <= TK_LDSK)) {
+                st->need = in_bin;       // the whole bin goes into the sort, which puts the wanted k_eff first
+                st->stop = 1;
+            } else {
+                st->need = need - above;
+            }
+        }
+        above = here;
+    }
+}
+
+__global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mode, int64_t sel, int n, int k, const double *eig,
+                                                                          const double *obj, TopkWs *ws, uint64_t *sel_key,
+                                                                          uint32_t *sel_idx)
+{
+    constexpr int NT = TK_SMALLSEL_THREADS, NW = NT / 64, R = TK_SMALLSEL_N / NT;      // R rows of NT candidates at most
+    __shared__ uint64_t surv[TK_SMALLSEL_N];     // keys that still match the prefix after the first pass
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t cnt[5];                  // class members, violated, positive, next free slot of the compaction, survivors
+    __shared__ uint32_t wave_cnt[NW][2];
+    __shared__ uint64_t wave_and[NW], wave_or[NW];
+    __shared__ SmallSelState st;
+    __shared__ int s_p0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef TK_SMALLSEL_TIMING      // debug build: phase stamps in 10 ns ticks, printed by thread 0
+    unsigned long long ph[8]; int nph = 0;
+#define SEL_STAMP() do { if (nph < 8) ph[nph++] = wall_clock64(); } while (0)
+#else
+#define SEL_STAMP()
+#endif
+    SEL_STAMP();
+    // the scores of the first eight rows are requested before the mode is resolved (they do not depend on it, the strong count
+    // is another trip to memory: ONE workgroup has nobody to hide either behind)
+    const int rows = (n + TK_SMALLSEL_THREADS - 1) / TK_SMALLSEL_THREADS;          // uniform
+    const double *pe = eig ? eig : obj, *po = obj ? obj : eig;      // a measure the mode does not use is never looked at
+    double e[8], o[8];
+    int64_t strong = 0;                          // (left by the score kernels of this round; requested first, returned first)
+#pragma unroll
+    for (int r = 0; r < TK_SREP; ++r) strong += ld_i64(&ws->strong_rep[r]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * TK_SMALLSEL_THREADS + t;
+        const int ic = i < n ? i : n - 1;
+        if (u < rows) {      // uniform
+            e[u] = pe[ic];
+            o[u] = po[ic];
+        }
+    }
+    if (mode == TK_MODE_COMBAUTO) mode = strong >= sel ? TK_MODE_STRONG : TK_MODE_COMBALL;
+    const bool all_members = mode == TK_MODE_OPT || mode == TK_MODE_COMBALL;
+    const bool comball = mode == TK_MODE_COMBALL;
+    if (t < 5) cnt[t] = 0;
+    if (t < 256) hist[t] = 0;
+    if (t == 0) { st.prefix = 0; st.stop = 0; st.is_void = 0; st.in_bin = 0; s_p0 = 0; }
+    __syncthreads();
+    // ---- keys of this thread's candidates (row r: candidate r * NT + t) in registers; class size, violated, positive; the bits
+    // all class members share
+    uint64_t key[R];
+    {
+        uint32_t c_class = 0, c_viol = 0, c_pos = 0;
+        uint64_t k_and = ~0ull, k_or = 0ull;
+        // (eight rows of loads in flight per thread)
+#pragma unroll
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            if (r0 > 0 && r0 < rows) {      // uniform
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = (r0 + u) * NT + t;
+                    const int ic = i < n ? i : n - 1;
+                    e[u] = pe[ic];
+                    o[u] = po[ic];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = (r0 + u) * NT + t;
+                uint64_t kk = 0ull;
+                if (r0 + u < rows && i < n) {
+                    const double ev = eig ? e[u] : 0.0, ov = obj ? o[u] : 0.0;
+                    kk = masked_key(mode, ev, ov);
+                    const bool member = all_members || kk != 0ull;
+                    c_class += member;
+                    k_and &= member ? kk : ~0ull;
+                    k_or |= member ? kk : 0ull;
+                    c_viol += (eig != nullptr) && (ev < SDPCUT_NEG_EIGVAL);
+                    c_pos += (obj != nullptr) && (ov > 0.0);
+                }
+                key[r0 + u] = kk;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            c_class += __shfl_xor((int)c_class, off);
+            c_viol += __shfl_xor((int)c_viol, off);
+            c_pos += __shfl_xor((int)c_pos, off);
+            k_and &= (uint64_t)__shfl_xor((long long)k_and, off);
+            k_or |= (uint64_t)__shfl_xor((long long)k_or, off);
+        }
+        if (lane == 0) {
+            if (c_class) atomicAdd(&cnt[0], c_class);
+            if (c_viol) atomicAdd(&cnt[1], c_viol);
+            if (c_pos) atomicAdd(&cnt[2], c_pos);
+            wave_and[wave] = k_and;
+            wave_or[wave] = k_or;
+        }
+    }
+    __syncthreads();
+    SEL_STAMP();      // [1] keys built
+    const int cls = (int)cnt[0];
+    const int k_eff = k < cls ? k : cls;
+    // what the early stop may hand to the sort: the tiles the head needs anyway, never more than the merge's LDS holds
+    int cap = (k_eff + TK_TILE - 1) / TK_TILE * TK_TILE;
+    cap = cap < TK_LDSK ? cap : TK_LDSK;
+    if (t == 0) {
+        ws->counters[0] = cls;
+        ws->counters[1] = cnt[1];
+        ws->counters[2] = cnt[2];
+        ws->counters[3] = k_eff;
+        ws->counters[5] = strong;
+        ws->counters[6] = mode;
+        ws->mode = mode;
+        st.need = k_eff;
+        uint64_t a = ~0ull, o = 0ull;
+        for (int w = 0; w < NW; ++w) { a &= wave_and[w]; o |= wave_or[w]; }
+        // leading bytes every class member agrees on: nothing to select there (key images of scores of one sign and similar size
+        // share two of their eight bytes or more).  A list with non-members (key 0) must not skip a prefix of zero bytes: the
+        // passes tell members from non-members by it.
+        int p0 = 0;
+        const uint64_t diff = a ^ o;
+        while (p0 < 7 && ((diff >> (8 * (7 - p0))) & 255ull) == 0ull) ++p0;
+        if (cls == 0 || (!all_members && p0 > 0 && (a >> (8 * (8 - p0))) == 0ull)) p0 = 0;
+        s_p0 = p0;
+        st.prefix = p0 ? (a >> (8 * (8 - p0))) << (8 * (8 - p0)) : 0ull;
+        if (cls <= cap) st.stop = 1;      // the whole class fits: no pass at all, every member goes to the sort (T = 0)
+    }
+    __syncthreads();
+    if (k_eff == 0) return;      // (n_sel stays 0 with the zeroed workspace)
+    // ---- MSD radix select: threshold key T (st.prefix) and how many of the keys equal to it are wanted.  The first pass runs over
+    // all keys (registers) and leaves the keys of the threshold bin in LDS; the later ones run over those survivors only.
+    int p = s_p0;
+    SEL_STAMP();      // [2] header
+    if (!st.stop) {
+        const int shift = 8 * (7 - p);
+        const uint64_t prefix = st.prefix;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r < rows) {      // uniform (every lane runs every row: hist_add is wave-cooperative)
+                const int i = r * NT + t;
+                const bool match = i < n && (p == 0 || ((key[r] ^ prefix) >> (shift + 8)) == 0);
+                hist_add(hist, (uint32_t)((key[r] >> shift) & 255), match);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, comball, ws);
+        __syncthreads();
+        if (!st.stop && !st.is_void && p < 7) {      // uniform: survivors = the keys of the threshold bin
+            const uint64_t pre = st.prefix;
+            // (ONE reservation per wave for all its rows: an LDS atomic with a return value per row is a round trip per row)
+            unsigned long long mrow[R];
+            uint32_t wtot = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                mrow[r] = 0ull;
+                if (r < rows) {      // uniform
+                    const int i = r * NT + t;
+                    mrow[r] = __ballot(i < n && ((key[r] ^ pre) >> shift) == 0);
+                    wtot += (uint32_t)__popcll(mrow[r]);
+                }
+            }
+            uint32_t wbase = 0;
+            if (lane == 0 && wtot) wbase = atomicAdd(&cnt[4], wtot);
+            wbase = (uint32_t)__shfl((int)wbase, 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r < rows) {
+                    if ((mrow[r] >> lane) & 1ull) surv[wbase + (uint32_t)__popcll(mrow[r] & ((1ull << lane) - 1ull))] = key[r];
+                    wbase += (uint32_t)__popcll(mrow[r]);
+                }
+            }
+            __syncthreads();
+        }
+        ++p;
+    }
+    SEL_STAMP();      // [3] first pass + survivors
+    for (; p < 8 && !st.stop && !st.is_void; ++p) {
+        const int shift = 8 * (7 - p);
+        const int ns = (int)cnt[4];              // every survivor matches the prefix down to the digit of this pass
+        for (int i0 = 0; i0 < ns; i0 += NT) {
+            const int i = i0 + t;
+            const uint64_t kk = i < ns ? surv[i] : 0ull;
+            const bool match = i < ns && ((kk ^ st.prefix) >> (shift + 8)) == 0;
+            hist_add(hist, (uint32_t)((kk >> shift) & 255), match);
+        }
+        __syncthreads();
+        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, comball, ws);
+        __syncthreads();
+    }
+    if (st.is_void) return;
+    SEL_STAMP();      // [4] later passes
+    const uint64_t T = st.prefix;
+    if (st.stop) {
+        // ---- early stop: every class member >= T (the lowest value of the threshold bin), in any order -- the sort orders them
+        unsigned long long mrow[R];
+        uint32_t wtot = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mrow[r] = 0ull;
+            if (r < rows) {      // uniform
+                const int i = r * NT + t;
+                mrow[r] = __ballot(i < n && key[r] >= T && (all_members || key[r] != 0ull));
+                wtot += (uint32_t)__popcll(mrow[r]);
+            }
+        }
+        uint32_t wbase = 0;
+        if (lane == 0 && wtot) wbase = atomicAdd(&cnt[3], wtot);      // (one reservation per wave)
+        wbase = (uint32_t)__shfl((int)wbase, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r < rows) {
+                if ((mrow[r] >> lane) & 1ull) {
+                    const uint32_t slot = wbase + (uint32_t)__popcll(mrow[r] & ((1ull << lane) - 1ull));
+                    sel_key[slot] = key[r];
+                    sel_idx[slot] = (uint32_t)(r * NT + t);
+                }
+                wbase += (uint32_t)__popcll(mrow[r]);
+            }
+        }
+        __syncthreads();
+        if (t == 0) ws->n_sel = cnt[3];
+#ifdef TK_SMALLSEL_TIMING
+        SEL_STAMP();
+        if (t == 0) printf("smallsel n %d k %d cls %d p0 %d last p %d n_sel %u: keys %llu header %llu pass1 %llu passes %llu compaction %llu (x 10 ns)\n", n, k, cls, s_p0, p, cnt[3],
+                           ph[1] - ph[0], ph[2] - ph[1], ph[3] - ph[2], ph[4] - ph[3], ph[5] - ph[4]);
+#endif
+        return;
+    }
+    // ---- all eight digits used: every key above T and, of the keys equal to T, the `need` lowest indices (index order)
+    const int need = st.need;
+    int greater = 0;
+    {
+        uint32_t g = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = r * NT + t;
+            g += r < rows && i < n && key[r] > T && (all_members || key[r] != 0ull);
+        }
+        for (int off = 32; off > 0; off >>= 1) g += __shfl_xor((int)g, off);
+        if (lane == 0) wave_cnt[wave][0] = g;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) greater += (int)wave_cnt[w][0];
+        __syncthreads();
+    }
+    int base_gt = 0, base_eq = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r < rows) {      // uniform
+            const int i = r * NT + t;
+            const bool member = i < n && (all_members || key[r] != 0ull);
+            const bool is_gt = member && key[r] > T;
+            const bool is_eq = member && key[r] == T;
+            const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
+            if (lane == 0) { wave_cnt[wave][0] = (uint32_t)__popcll(mg); wave_cnt[wave][1] = (uint32_t)__popcll(me); }
+            __syncthreads();
+            int bg = base_gt, be = base_eq, tg = 0, te = 0;
+            for (int w = 0; w < NW; ++w) {
+                if (w < wave) { bg += (int)wave_cnt[w][0]; be += (int)wave_cnt[w][1]; }
+                tg += (int)wave_cnt[w][0];
+                te += (int)wave_cnt[w][1];
+            }
+            if (is_gt) {
+                const int slot = bg + __popcll(mg & ((1ull << lane) - 1ull));
+                sel_key[slot] = key[r];
+                sel_idx[slot] = (uint32_t)i;
+            }
+            if (is_eq) {
+                const int q = be + __popcll(me & ((1ull << lane) - 1ull));
+                if (q < need) {
+                    sel_key[greater + q] = key[r];
+                    sel_idx[greater + q] = (uint32_t)i;
+                }
+            }
+            base_gt += tg;
+            base_eq += te;
+            __syncthreads();
+        }
+    }
+    if (t == 0) ws->n_sel = greater + (base_eq < need ? base_eq : need);
 }
 
 // Everything behind pass 0: the remaining digit passes, the compaction, the sort and the ranks.
@@ -1028,8 +1380,12 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    const bool small = !digit_done && n <= maxk;
-    if (small) {
+    const bool smallsel = !digit_done && smallsel_range(n, k, mode == TK_MODE_COMBAUTO || mode == TK_MODE_COMBALL);
+    const bool small = smallsel || (!digit_done && n <= maxk);
+    if (smallsel) {
+        hipLaunchKernelGGL(tk_smallsel_kernel, dim3(1), dim3(TK_SMALLSEL_THREADS), 0, h->stream, mode, sel, (int)n, (int)k, eig, obj, ws,
+                           h->d_sel_key, h->d_sel_idx);
+    } else if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_SMALL_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);
     } else if (!digit_done) {

@@ -12,6 +12,12 @@
 #define TK_LDSK 8192     // heads whose compacted superset (keys AND indices) fits the merge kernel's LDS
 #define TK_MAXK 16384    // largest head: the merge keeps the keys in LDS and reads indices only on ties
 #define TK_UNROLL 8      // grid-stride rounds whose loads are issued together
+// lists of at most TK_SMALLSEL_N candidates with a head of at most TK_LDSK: selection by ONE workgroup, keys in LDS (tk_smallsel_kernel)
+#ifndef TK_SMALLSEL
+#define TK_SMALLSEL 1
+#endif
+#define TK_SMALLSEL_N 16384
+#define TK_SMALLSEL_THREADS 1024
 // Replicas of the global histogram: same-address device-scope atomics are serialised at ~15-20 ns
 // each, so 256 workgroups flushing into ONE row cost ~5 us per pass; block b adds into replica
 // b % TK_HREP (32 adds per cell) and the resolving block sums the replicas.

@@ -245,3 +245,56 @@ def test_lambda_min_on_points_outside_the_lp_box(oracle, k):
             assert err.max() <= 3e-15, (pi, float(err.max()))      # (two backward-stable solvers: a few ulp of the norm apart)
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("count", [3500, 8192, 12000])
+@pytest.mark.parametrize("distinct", [None, 0, 2, 12])
+def test_short_list_selection_in_one_workgroup(oracle, count, distinct):
+    """Lists of a few thousand candidates (most covers of the paper's instances) are selected by ONE workgroup with the keys in
+    registers / LDS (tk_smallsel_kernel, round 4): early stop on a superset of whole tiles, the cut of a tie group by index at the
+    last digit, the whole tie group of the every-entry-visited regime, and -- a group of more than 8192 equal new scores -- the
+    void selection answered by topk_tie_split.  Every route gives the oracle's ranking of the device's own scores, bit for bit,
+    without the library sort.  distinct = None: a generic point; otherwise x = 0.5, X = 0.1 but for `distinct` rows (a handful
+    of eigenvalues shared by thousands of candidates)."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    n = 60
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=count, seed=31)
+    if distinct is None:
+        vv = wl["vars_values"]
+    else:
+        X = np.full((n, n), 0.1)
+        for v in range(distinct):
+            X[v, :] = X[:, v] = 0.1 + 0.01 * (v + 1)
+        vv = np.concatenate([X[np.triu_indices(n)], np.full(n, 0.5)])
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(3)
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        big_group = False
+        for strat in (1, 2, 4):
+            for sel in (7, count // 20, count // 3, min(count, 8192)):
+                order, score, new_strat, cnt = oracle.rank_arrays(strat, obj, eig, sel)
+                w = min(sel, order.shape[0])
+                if strat == 4 and int(((obj > 0) & (eig < -1e-15)).sum()) < sel and w > 0:      # every entry visited: the tie group at the cut and everything above it
+                    big_group |= int((score >= score[w - 1]).sum()) > 8192 and int((score == score[w - 1]).sum()) > 1
+                for route in ("round_csr", "rank"):
+                    if route == "round_csr":
+                        r = sc.round_csr(strat, sel, point=vv)
+                        ids, sco, ns = r["idx"], r["score"], r["new_strat"]
+                    else:
+                        ids, sco, _, ns, _ = sc.rank(strat, sel, max_out=sel)
+                    assert ids.shape[0] == w and np.array_equal(ids, order[:w]), (strat, sel, route, int((ids != order[:w]).sum()))
+                    assert np.array_equal(sco, score[:w] + 0.0) and ns == new_strat, (strat, sel, route)
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+        # a tie group of the every-entry-visited regime beyond the merge's 8192 entries: declared void by the kernel, cut by
+        # (obj_improve, index) with two more selections
+        assert (sc.get_stat(_capi.STAT_TIE_SPLITS) > 0) == big_group, (count, distinct, big_group, sc.get_stat(_capi.STAT_TIE_SPLITS))
+        if count == 12000 and distinct == 0:
+            assert big_group
+    finally:
+        sc.close()
