@@ -857,13 +857,24 @@ int64_t *topk_strong_counter(void *ws) { return ((TopkWs *)ws)->strong_rep; }
 static bool smallsel_range(int64_t n, int64_t k, bool comb)
 {
     if (!TK_SMALLSEL || k > TK_LDSK || n > TK_SMALLSEL_N) return false;
+    // (a head of more than a quarter of the list -- the 5000 of a 7899-candidate QCQP cover -- is not worth selecting: the
+    // threshold lies deep in the list, five or six passes and the cut by index, 32 us where sorting the whole class takes 39 - 14)
+    if (4 * k > n) return false;
     return comb ? (n > 2048 && n <= 12288) : (n > 3072 && n <= 8192);
+}
+
+// ... and with the sort inside (heads of one tile at most, no shard record to write behind the head): lists of at most 4096
+// candidates -- ONE launch instead of three, 55 -> 47 us per combined round on 64 candidates, 68 -> 59 on 2048, 70 -> 66 on 4096;
+// beyond that the four waves that sort lose to the tile-sort launch what the saved hand-offs gain (same evidence file)
+static bool smallsort_range(const sdpcut_ctx *h, int64_t n, int64_t k)
+{
+    return TK_SMALLSEL && TK_SMALLSORT && k <= TK_TILE && n <= 4096 && !h->shard_rec;
 }
 
 bool topk_fuse_ok(const sdpcut_ctx *h, int64_t k, bool comb)
 {
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    if (smallsel_range(h->N, k, comb)) return false;      // tk_smallsel_kernel builds its own keys: nothing to count
+    if (smallsel_range(h->N, k, comb) || smallsort_range(h, h->N, k)) return false;      // tk_smallsel_kernel builds its own keys: nothing to count
     return h->fused_tail && !h->coop_launch && k >= 1 && k <= TK_MAXK && h->N > maxk;
 }
 
@@ -953,7 +964,8 @@ struct SmallSelState {
     uint64_t prefix;
     int need, stop, is_void, in_bin;
 };
-__device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *st, int p, int k_eff, int cap, bool comball, TopkWs *ws)
+__device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *st, int p, int k_eff, int cap, int group_max, bool comball,
+                                                 TopkWs *ws)
 {
     const int lane = threadIdx.x & 63;
     uint32_t h[4];
@@ -978,8 +990,8 @@ __device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *
             const int in_bin = (int)h[j];
             const int superset = k_eff - (need - above) + in_bin;      // every key >= the bin's lowest value
             const bool whole_group = p == 7 && comball && in_bin > need - above;      // a tie group that is ordered by obj_improve
-            if (whole_group && superset > TK_LDSK) {
-                // more equal new scores at the threshold than the merge holds: void, flag 2; T and the number still wanted from
+            if (whole_group && superset > group_max) {
+                // more equal new scores at the threshold than the sort holds: void, flag 2; T and the number still wanted from
                 // the group for topk_tie_split
                 st->is_void = 1;
                 ws->counters[4] = 2;
@@ -989,7 +1001,7 @@ __device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *
             }
             st->prefix = pre;
             st->in_bin = in_bin;
-            if ((p < 7 && superset <= cap) || (p == 7 && comball && superset <= TK_LDSK)) {
+            if ((p < 7 && superset <= cap) || (p == 7 && comball && superset <= group_max)) {
                 st->need = in_bin;       // the whole bin goes into the sort, which puts the wanted k_eff first
                 st->stop = 1;
             } else {
@@ -1000,12 +1012,44 @@ __device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *
     }
 }
 
+// SORT (heads of at most TK_TILE entries, the usual 5-10 % of a short list): the superset is at most one tile -- it stays in LDS,
+// the first four waves sort it (bitonic, (key desc, [obj_improve desc,] index asc): tk_tilesort_kernel's network) and emit the head.
+// The round's selection is ONE launch instead of three (tile sort and merge ranks have nothing left to do); an every-entry-visited
+// tie group of more than TK_SORTMAX entries is declared void like a group beyond the merge's LDS in the other variant.
+#define TK_SORTMAX 2048
+template <bool TIE>
+__device__ __forceinline__ void smallsel_sort(uint64_t *sk, uint32_t *si, int P, const double *obj)
+{
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int q = threadIdx.x; q < (P >> 1); q += 256) {
+                const int pos = 2 * q - (q & (stride - 1));
+                const int par = pos + stride;
+                const bool up = (pos & size) == 0;
+                const uint64_t ka = sk[pos], kb = sk[par];
+                const uint32_t ia = si[pos], ib = si[par];
+                if (comp_less<TIE>(kb, ib, ka, ia, obj) == up) {
+                    sk[pos] = kb; sk[par] = ka;
+                    si[pos] = ib; si[par] = ia;
+                }
+            }
+            __syncthreads();      // (the four waves that are left: the others have ended)
+        }
+    }
+}
+
+template <bool SORT>
 __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mode, int64_t sel, int n, int k, const double *eig,
                                                                           const double *obj, TopkWs *ws, uint64_t *sel_key,
-                                                                          uint32_t *sel_idx)
+                                                                          uint32_t *sel_idx, int64_t base, double score_add,
+                                                                          int64_t *idx_out, double *score_out)
 {
     constexpr int NT = TK_SMALLSEL_THREADS, NW = NT / 64, R = TK_SMALLSEL_N / NT;      // R rows of NT candidates at most
     __shared__ uint64_t surv[TK_SMALLSEL_N];     // keys that still match the prefix after the first pass
+    __shared__ uint64_t sk[SORT ? TK_SORTMAX : 1];      // SORT: the superset, inverted keys (ascending composite order)
+    __shared__ uint32_t si[SORT ? TK_SORTMAX : 1];
+    const bool auto_mode = mode == TK_MODE_COMBAUTO;
+    const int group_max = SORT ? TK_SORTMAX : TK_LDSK;
     __shared__ uint32_t hist[256];
     __shared__ uint32_t cnt[5];                  // class members, violated, positive, next free slot of the compaction, survivors
     __shared__ uint32_t wave_cnt[NW][2];
@@ -1056,6 +1100,7 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             if (r0 > 0 && r0 < rows) {      // uniform
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    if (r0 + u >= R) continue;      // (compile time)
                     const int i = (r0 + u) * NT + t;
                     const int ic = i < n ? i : n - 1;
                     e[u] = pe[ic];
@@ -1064,6 +1109,7 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                if (r0 + u >= R) continue;          // (compile time)
                 const int i = (r0 + u) * NT + t;
                 uint64_t kk = 0ull;
                 if (r0 + u < rows && i < n) {
@@ -1101,6 +1147,7 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
     // what the early stop may hand to the sort: the tiles the head needs anyway, never more than the merge's LDS holds
     int cap = (k_eff + TK_TILE - 1) / TK_TILE * TK_TILE;
     cap = cap < TK_LDSK ? cap : TK_LDSK;
+    if (SORT) cap = TK_TILE;      // (k <= TK_TILE: the launch's condition)
     if (t == 0) {
         ws->counters[0] = cls;
         ws->counters[1] = cnt[1];
@@ -1141,7 +1188,7 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             }
         }
         __syncthreads();
-        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, comball, ws);
+        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, group_max, comball, ws);
         __syncthreads();
         if (!st.stop && !st.is_void && p < 7) {      // uniform: survivors = the keys of the threshold bin
             const uint64_t pre = st.prefix;
@@ -1160,16 +1207,61 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             uint32_t wbase = 0;
             if (lane == 0 && wtot) wbase = atomicAdd(&cnt[4], wtot);
             wbase = (uint32_t)__shfl((int)wbase, 0);
+            uint64_t s_and = ~0ull, s_or = 0ull;      // the bits the survivors share
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (r < rows) {
-                    if ((mrow[r] >> lane) & 1ull) surv[wbase + (uint32_t)__popcll(mrow[r] & ((1ull << lane) - 1ull))] = key[r];
+                    if ((mrow[r] >> lane) & 1ull) {
+                        surv[wbase + (uint32_t)__popcll(mrow[r] & ((1ull << lane) - 1ull))] = key[r];
+                        s_and &= key[r];
+                        s_or |= key[r];
+                    }
                     wbase += (uint32_t)__popcll(mrow[r]);
                 }
             }
+            for (int off = 32; off > 0; off >>= 1) {
+                s_and &= (uint64_t)__shfl_xor((long long)s_and, off);
+                s_or |= (uint64_t)__shfl_xor((long long)s_or, off);
+            }
+            if (lane == 0) { wave_and[wave] = s_and; wave_or[wave] = s_or; }
             __syncthreads();
+            // Structured LP points: the threshold bin is ONE value shared by hundreds or thousands of candidates (a QCQP cover
+            // of 7899: eight passes to the last digit, 30 us).  The bytes all survivors share are skipped; if they share all of
+            // them the selection is finished here -- the group is cut by index below, or, in the every-entry-visited regime, taken
+            // whole / declared void exactly as the last digit would have done.
+            if (t == 0) {
+                uint64_t a = ~0ull, o = 0ull;
+                for (int w = 0; w < NW; ++w) { a &= wave_and[w]; o |= wave_or[w]; }
+                const uint64_t diff = a ^ o;
+                const int ns = (int)cnt[4], need = st.need;
+                int pn = p + 1;
+                while (pn < 8 && ((diff >> (8 * (7 - pn))) & 255ull) == 0ull) ++pn;
+                if (pn == 8) {      // one value
+                    const int superset = k_eff - need + ns;
+                    st.prefix = a;
+                    st.in_bin = ns;
+                    if (comball && ns > need) {
+                        if (superset <= group_max) {
+                            st.need = ns;
+                            st.stop = 1;
+                        } else {
+                            st.is_void = 1;
+                            ws->counters[4] = 2;
+                            ws->state[8].prefix = a;
+                            ws->state[8].need = need;
+                            ws->state[8].stop = 0;
+                        }
+                    }
+                } else {
+                    st.prefix = (a >> (8 * (8 - pn))) << (8 * (8 - pn));
+                }
+                s_p0 = pn;
+            }
+            __syncthreads();
+            p = s_p0;
+        } else {
+            ++p;
         }
-        ++p;
     }
     SEL_STAMP();      // [3] first pass + survivors
     for (; p < 8 && !st.stop && !st.is_void; ++p) {
@@ -1182,7 +1274,7 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             hist_add(hist, (uint32_t)((kk >> shift) & 255), match);
         }
         __syncthreads();
-        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, comball, ws);
+        if (wave == 0) smallsel_resolve(hist, &st, p, k_eff, cap, group_max, comball, ws);
         __syncthreads();
     }
     if (st.is_void) return;
@@ -1209,14 +1301,34 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             if (r < rows) {
                 if ((mrow[r] >> lane) & 1ull) {
                     const uint32_t slot = wbase + (uint32_t)__popcll(mrow[r] & ((1ull << lane) - 1ull));
-                    sel_key[slot] = key[r];
-                    sel_idx[slot] = (uint32_t)(r * NT + t);
+                    if constexpr (SORT) {
+                        sk[slot] = ~key[r];
+                        si[slot] = (uint32_t)(r * NT + t);
+                    } else {
+                        sel_key[slot] = key[r];
+                        sel_idx[slot] = (uint32_t)(r * NT + t);
+                    }
                 }
                 wbase += (uint32_t)__popcll(mrow[r]);
             }
         }
         __syncthreads();
-        if (t == 0) ws->n_sel = cnt[3];
+        if (t == 0) ws->n_sel = SORT ? k_eff : (int)cnt[3];
+        if constexpr (SORT) {
+            const int M = (int)cnt[3];
+            int P = 64;
+            while (P < M) P <<= 1;
+            for (int j = M + t; j < P; j += NT) { sk[j] = ~0ull; si[j] = 0xffffffffu; }      // padding sorts last
+            __syncthreads();
+            if (wave >= 4) return;      // (ended waves leave the workgroup's barriers)
+            if (comball) smallsel_sort<true>(sk, si, P, obj);
+            else smallsel_sort<false>(sk, si, P, obj);
+            const double add = (auto_mode && comball) ? 0.0 : score_add;      // (device-resolved regime: BIG_M belongs to the strong class only)
+            for (int r = t; r < k_eff; r += 256) {
+                idx_out[r] = base + (int64_t)si[r];
+                score_out[r] = score_of(~sk[r]) + add;
+            }
+        }
 #ifdef TK_SMALLSEL_TIMING
         SEL_STAMP();
         if (t == 0) printf("smallsel n %d k %d cls %d p0 %d last p %d n_sel %u: keys %llu header %llu pass1 %llu passes %llu compaction %llu (x 10 ns)\n", n, k, cls, s_p0, p, cnt[3],
@@ -1240,41 +1352,72 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
         for (int w = 0; w < NW; ++w) greater += (int)wave_cnt[w][0];
         __syncthreads();
     }
-    int base_gt = 0, base_eq = 0;
+    // counts per (row, wave) in one table: the offsets of the index-ordered compaction need ONE barrier, not two per row
+    __shared__ uint16_t tab_gt[R][NW], tab_eq[R][NW];
+    unsigned long long mg[R], me[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        mg[r] = me[r] = 0ull;
         if (r < rows) {      // uniform
             const int i = r * NT + t;
             const bool member = i < n && (all_members || key[r] != 0ull);
-            const bool is_gt = member && key[r] > T;
-            const bool is_eq = member && key[r] == T;
-            const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
-            if (lane == 0) { wave_cnt[wave][0] = (uint32_t)__popcll(mg); wave_cnt[wave][1] = (uint32_t)__popcll(me); }
-            __syncthreads();
+            mg[r] = __ballot(member && key[r] > T);
+            me[r] = __ballot(member && key[r] == T);
+            if (lane == 0) { tab_gt[r][wave] = (uint16_t)__popcll(mg[r]); tab_eq[r][wave] = (uint16_t)__popcll(me[r]); }
+        }
+    }
+    __syncthreads();
+    int base_gt = 0, base_eq = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r < rows) {
             int bg = base_gt, be = base_eq, tg = 0, te = 0;
             for (int w = 0; w < NW; ++w) {
-                if (w < wave) { bg += (int)wave_cnt[w][0]; be += (int)wave_cnt[w][1]; }
-                tg += (int)wave_cnt[w][0];
-                te += (int)wave_cnt[w][1];
+                const int cg = tab_gt[r][w], ce = tab_eq[r][w];
+                if (w < wave) { bg += cg; be += ce; }
+                tg += cg;
+                te += ce;
             }
-            if (is_gt) {
-                const int slot = bg + __popcll(mg & ((1ull << lane) - 1ull));
-                sel_key[slot] = key[r];
-                sel_idx[slot] = (uint32_t)i;
+            const int i = r * NT + t;
+            if ((mg[r] >> lane) & 1ull) {
+                const int slot = bg + __popcll(mg[r] & ((1ull << lane) - 1ull));
+                if constexpr (SORT) { sk[slot] = ~key[r]; si[slot] = (uint32_t)i; }
+                else { sel_key[slot] = key[r]; sel_idx[slot] = (uint32_t)i; }
             }
-            if (is_eq) {
-                const int q = be + __popcll(me & ((1ull << lane) - 1ull));
+            if ((me[r] >> lane) & 1ull) {
+                const int q = be + __popcll(me[r] & ((1ull << lane) - 1ull));
                 if (q < need) {
-                    sel_key[greater + q] = key[r];
-                    sel_idx[greater + q] = (uint32_t)i;
+                    if constexpr (SORT) { sk[greater + q] = ~key[r]; si[greater + q] = (uint32_t)i; }
+                    else { sel_key[greater + q] = key[r]; sel_idx[greater + q] = (uint32_t)i; }
                 }
             }
             base_gt += tg;
             base_eq += te;
-            __syncthreads();
         }
     }
-    if (t == 0) ws->n_sel = greater + (base_eq < need ? base_eq : need);
+    __syncthreads();
+    const int M = greater + (base_eq < need ? base_eq : need);      // = k_eff
+    if (t == 0) ws->n_sel = M;
+#ifdef TK_SMALLSEL_TIMING
+    SEL_STAMP();
+    if (t == 0) printf("smallsel n %d k %d cls %d p0 %d survivors %u, exact cut, greater %d need %d: keys %llu header %llu pass1 %llu passes %llu compaction %llu (x 10 ns)\n", n, k, cls, s_p0,
+                       cnt[4], greater, need, ph[1] - ph[0], ph[2] - ph[1], ph[3] - ph[2], ph[4] - ph[3], ph[5] - ph[4]);
+#endif
+    if constexpr (SORT) {
+        int P = 64;
+        while (P < M) P <<= 1;
+        for (int j = M + t; j < P; j += NT) { sk[j] = ~0ull; si[j] = 0xffffffffu; }
+        __syncthreads();
+        if (wave >= 4) return;
+        // (the every-entry-visited regime gets here only with a tie group that is wanted whole: its members still go by obj_improve)
+        if (comball) smallsel_sort<true>(sk, si, P, obj);
+        else smallsel_sort<false>(sk, si, P, obj);
+        const double add = (auto_mode && comball) ? 0.0 : score_add;
+        for (int r = t; r < k_eff; r += 256) {
+            idx_out[r] = base + (int64_t)si[r];
+            score_out[r] = score_of(~sk[r]) + add;
+        }
+    }
 }
 
 // Everything behind pass 0: the remaining digit passes, the compaction, the sort and the ranks.
@@ -1380,11 +1523,20 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
     int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < TK_MAXBLK ? nb : TK_MAXBLK);
     const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-    const bool smallsel = !digit_done && smallsel_range(n, k, mode == TK_MODE_COMBAUTO || mode == TK_MODE_COMBALL);
+    const bool comb = mode == TK_MODE_COMBAUTO || mode == TK_MODE_COMBALL;
+    if (!digit_done && smallsort_range(h, n, k)) {
+        // a short list with a head of one tile at most: selection, sort and emission in ONE launch
+        hipLaunchKernelGGL(tk_smallsel_kernel<true>, dim3(1), dim3(TK_SMALLSEL_THREADS), 0, h->stream, mode, sel, (int)n, (int)k, eig, obj,
+                           ws, h->d_sel_key, h->d_sel_idx, h->base, score_add, d_idx_out, d_score_out);
+        HIP_TRY(h, hipGetLastError());
+        if (d_counters_out) *d_counters_out = ws->counters;
+        return 0;
+    }
+    const bool smallsel = !digit_done && smallsel_range(n, k, comb);
     const bool small = smallsel || (!digit_done && n <= maxk);
     if (smallsel) {
-        hipLaunchKernelGGL(tk_smallsel_kernel, dim3(1), dim3(TK_SMALLSEL_THREADS), 0, h->stream, mode, sel, (int)n, (int)k, eig, obj, ws,
-                           h->d_sel_key, h->d_sel_idx);
+        hipLaunchKernelGGL(tk_smallsel_kernel<false>, dim3(1), dim3(TK_SMALLSEL_THREADS), 0, h->stream, mode, sel, (int)n, (int)k, eig, obj,
+                           ws, h->d_sel_key, h->d_sel_idx, h->base, score_add, d_idx_out, d_score_out);
     } else if (small) {
         hipLaunchKernelGGL(tk_small_kernel, dim3(1), dim3(TK_SMALL_THREADS), 0, h->stream, mode, sel, n, k, eig, obj, ws, h->d_sel_key,
                            h->d_sel_idx);

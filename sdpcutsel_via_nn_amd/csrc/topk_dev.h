@@ -16,7 +16,10 @@
 #ifndef TK_SMALLSEL
 #define TK_SMALLSEL 1
 #endif
-#define TK_SMALLSEL_N 16384
+#ifndef TK_SMALLSORT
+#define TK_SMALLSORT 1     // ... and, for heads of one tile at most, sorted and emitted by it too (ONE launch for the round's selection)
+#endif
+#define TK_SMALLSEL_N 12288
 #define TK_SMALLSEL_THREADS 1024
 // Replicas of the global histogram: same-address device-scope atomics are serialised at ~15-20 ns
 // each, so 256 workgroups flushing into ONE row cost ~5 us per pass; block b adds into replica

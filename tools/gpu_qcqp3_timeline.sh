@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel timeline of a QCQP dim-3 round: tools/gpu_qcqp3_timeline.sh <qcqp golden npz> <round> <out name>
+# kernel timeline of a QCQP dim-3 round: tools/gpu_qcqp3_timeline.sh <qcqp golden npz> <round> <out name>   (SDPCUT_LIB=... for a variant library)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_$3
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$3 -o prof -f csv -- python3 tools/qcqp3_time.py $1 $2 40 > gpurun_out/prof_$3.log 2>&1 || exit 1
