@@ -1420,6 +1420,8 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
     }
 }
 
+#undef SEL_STAMP
+
 // Everything behind pass 0: the remaining digit passes, the compaction, the sort and the ranks.
 // n keys in h->d_key_a; k <= TK_MAXK; raw: see tk_mergerank_big_kernel (heads > TK_LDSK only).
 // onfly: pass 0 was counted by the score kernels and there are no keys (tk_refine_kernel<true>; eig / obj /
