@@ -298,3 +298,42 @@ def test_short_list_selection_in_one_workgroup(oracle, count, distinct):
             assert big_group
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("count", [3500, 9000])
+def test_short_list_tie_group_beyond_the_sort_buffers(oracle, count):
+    """The void branch of both variants of tk_smallsel_kernel: a list of `count` candidates at a structured point of which a few
+    dozen are strong and all others share ONE new score -lambda_min (every entry visited, their order is by obj_improve): the tie
+    group at the cut exceeds what the kernel can sort itself (2048 entries, lists <= 4096 with heads <= 512) or hand to the merge
+    (8192), the selection is declared void on the device and topk_tie_split cuts the group -- no library sort, bit-identical."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, synthetic
+    n = 100
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=120000, seed=7)
+    vv = np.concatenate([np.full((n, n), 0.1)[np.triu_indices(n)], np.full(n, 0.5)])
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(3)
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig0, obj0 = sc.get_scores()
+        keep = np.sort(np.concatenate([np.flatnonzero(obj0 <= 0)[:count - 30], np.flatnonzero(obj0 > 0)[:30]]))
+        assert keep.size == count
+        sc.set_candidates(wl["set_inds"][keep], wl["ks"][keep])
+        sc.set_point(vv)
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = sc.get_scores()
+        assert np.unique(eig).size == 1 and (eig < -1e-15).all()
+        for sel in (count // 20, 500):
+            order, score, new_strat, cnt = oracle.rank_arrays(4, obj, eig, sel)
+            before = sc.get_stat(_capi.STAT_TIE_SPLITS)
+            r = sc.round_csr(4, sel, point=vv)
+            assert np.array_equal(r["idx"], order[:sel]) and np.array_equal(r["score"], score[:sel] + 0.0) and r["new_strat"] == new_strat
+            ids, sco, _, ns, _ = sc.rank(4, sel, max_out=sel)
+            assert np.array_equal(ids, order[:sel]) and np.array_equal(sco, score[:sel] + 0.0) and ns == new_strat
+            assert sc.get_stat(_capi.STAT_TIE_SPLITS) - before == 2, (count, sel)
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+    finally:
+        sc.close()
