@@ -281,7 +281,12 @@ def test_short_list_selection_in_one_workgroup(oracle, count, distinct):
                 order, score, new_strat, cnt = oracle.rank_arrays(strat, obj, eig, sel)
                 w = min(sel, order.shape[0])
                 if strat == 4 and int(((obj > 0) & (eig < -1e-15)).sum()) < sel and w > 0:      # every entry visited: the tie group at the cut and everything above it
-                    big_group |= int((score >= score[w - 1]).sum()) > 8192 and int((score == score[w - 1]).sum()) > 1
+                    # (what the kernel can order itself: 2048 entries where it also sorts -- heads <= 512 on lists <= 4096 --,
+                    # else the 8192 of the merge)
+                    limit = 2048 if (count <= 4096 and sel <= 512) else 8192
+                    group = int((score == score[w - 1]).sum())
+                    wanted = w - int((score > score[w - 1]).sum())
+                    big_group |= int((score >= score[w - 1]).sum()) > limit and group > wanted
                 for route in ("round_csr", "rank"):
                     if route == "round_csr":
                         r = sc.round_csr(strat, sel, point=vv)
