@@ -35,6 +35,12 @@ struct ScoreArgs {
     int64_t n;
     // score_mfma_kernel: candidates per strip of a wave, 64 or 32 (launch_score_k; see the kernel)
     int32_t strip;
+    // Balanced tail round (r4, set_balanced_tail): candidates [0, rr_end) go round-robin in whole strips as before; the rest --
+    // less than one strip per wave -- is split EVENLY: wave g takes tail_hi (g < tail_nhi) or tail_lo column tiles of 16
+    // candidates from rr_end on.  rr_end = n, tail_hi = tail_lo = 0: no tail (every list but the ones the rule below picks).
+    int64_t rr_end;
+    int64_t tail_nhi;
+    int32_t tail_hi, tail_lo;
     const double *vars;   // [L + nv]: X packed | x
     const double *Q;      // [L]
     int32_t nv;
@@ -508,6 +514,17 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     const int64_t gw = (int64_t)bid * 4 + wave;
     const int64_t wstride = (int64_t)nblk * 4 * A.strip;      // candidates between two strips of one wave
     const int64_t c_first = gw * A.strip;
+    // ... and the LAST round of a list of a few rounds, when it is nearly full (r4): 10^6 candidates are 7.63 strips per resident
+    // wave slot, every slot ran 8 -- 4.6 % of the kernel idle at its end.  Now the round-robin part ends at the last FULL round
+    // (rr_end) and what is left is split evenly in column tiles of 16: three or four per wave (a three-tile strip = one two-tile
+    // pass + one single-tile pass), every workgroup the same for its four waves.
+    const int64_t t_tiles = gw < A.tail_nhi ? A.tail_hi : A.tail_lo;
+    const int64_t t_start0 = A.rr_end + 16 * (gw < A.tail_nhi ? gw * A.tail_hi : A.tail_nhi * A.tail_hi + (gw - A.tail_nhi) * A.tail_lo);
+    const int64_t t_start = t_start0 < A.n ? t_start0 : A.n;
+    const int64_t t_end = t_start + 16 * t_tiles < A.n ? t_start + 16 * t_tiles : A.n;      // (empty when t_start == t_end)
+    bool tail = c_first >= A.rr_end;                  // this wave's current strip is its tail strip
+    int64_t s0 = tail ? t_start : c_first;
+    bool more = tail ? t_start < t_end : true;
 
     // The index set (and the output slot) of the NEXT strip are requested before phase B of the
     // current one: the first of the two dependent memory round trips of phase A (HBM: indices, then
@@ -516,9 +533,10 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     // workgroup's start overlap.)
     int32_t s_nxt[K];
     int32_t orig_nxt = 0;
-    if (c_first < A.n) {
-        const int64_t c0 = c_first + lane;
-        const int64_t cc0 = (c0 < A.n && lane < A.strip) ? c0 : c_first;
+    if (more) {
+        const int64_t lim0 = tail ? t_end : (s0 + A.strip < A.rr_end ? s0 + A.strip : A.rr_end);
+        const int64_t c0 = s0 + lane;
+        const int64_t cc0 = c0 < lim0 ? c0 : s0;
         load_index_set<K>(s_nxt, A.set, A.n, cc0);
         orig_nxt = A.orig[cc0];
     }
@@ -547,24 +565,28 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     }
 
     PHASE_DECL;
-    for (int64_t s0 = c_first; s0 < A.n; s0 += wstride) {
+    while (more) {
         PHASE_MARK(0);
+        const int64_t lim = tail ? t_end : (s0 + A.strip < A.rr_end ? s0 + A.strip : A.rr_end);      // one past this strip's last candidate
+        // the strip after this one: the next round-robin strip, or the tail strip behind the last of them
+        const bool nx_rr = !tail && s0 + wstride < A.rr_end;
+        const bool nx_tail = !tail && !nx_rr;
+        const int64_t nx_s0 = nx_rr ? s0 + wstride : t_start;
+        const int64_t nx_lim = nx_rr ? (nx_s0 + A.strip < A.rr_end ? nx_s0 + A.strip : A.rr_end) : t_end;
+        const bool nx_more = nx_rr || (nx_tail && t_start < t_end);
         const int64_t c = s0 + lane;
-        const bool valid = c < A.n && lane < A.strip;
+        const bool valid = c < lim;
         int32_t s_cur[K];
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
         const int32_t out_idx = orig_nxt;
         Cand<K> cd;
         gather_candidate<K>(cd, s_cur, A.vars, A.Q, A.nv, A.L, (A.flags & SDPCUT_NN) != 0);
-        {
-            const int64_t sn = s0 + wstride;
-            if (sn < A.n) {                  // uniform per wave
-                const int64_t c1 = sn + lane;
-                const int64_t cc1 = (c1 < A.n && lane < A.strip) ? c1 : sn;
-                load_index_set<K>(s_nxt, A.set, A.n, cc1);
-                orig_nxt = A.orig[cc1];
-            }
+        if (nx_more) {                       // uniform per wave
+            const int64_t c1 = nx_s0 + lane;
+            const int64_t cc1 = c1 < nx_lim ? c1 : nx_s0;
+            load_index_set<K>(s_nxt, A.set, A.n, cc1);
+            orig_nxt = A.orig[cc1];
         }
 
         double lam = 0.0;
@@ -581,6 +603,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
                 c_viol += viol;
             }
+            tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
             continue;
         }
 
@@ -769,7 +792,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
             }
         };
         {
-            const int units = (int)(((A.n - s0 < A.strip ? A.n - s0 : A.strip) + 15) >> 4);      // column tiles of this strip that hold candidates
+            const int units = (int)((lim - s0 + 15) >> 4);      // column tiles of this strip that hold candidates
             // (a whole strip has its own loop with a constant trip count, and the rare paths are marked so: with one generic loop
             // the 5-variable kernel ran 1.5 % slower than before the split, this way 0.8 %, the 3- and 4-variable ones 1 % faster)
             if (__builtin_expect(units == 4, 1)) {
@@ -804,6 +827,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
         PHASE_MARK(4);
+        tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
     }
     PHASE_REPORT;
     if (A.strong_out) {      // uniform: one no-return atomic per workgroup, into one of eight replicas
@@ -1202,6 +1226,31 @@ static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
            (K == 4 && nd.width == 50 && nd.n_hidden == 3) || (K == 5 && nd.width == 64 && nd.n_hidden == 4);
 }
 
+// The balanced tail round of ScoreArgs (see score_mfma_body): for lists whose last round-robin round would be at least 90 % full
+// -- every resident slot then pays a whole strip for it -- the round is split evenly instead, three or four column tiles per wave,
+// the four waves of a workgroup alike.  Emptier last rounds are left alone: the two waves of a SIMD share its issue slots, the
+// dispatcher fills the gaps with the short workgroups, and a partial strip pays phase A for 64 lanes whatever it holds.  Measured
+// (k = 3, this rule against none, profiles/r04_balanced_tail.txt): kernel time over the list length is a plateau up to a fill of
+// 0.875 and steps up at 0.9; with the split the step becomes a ramp: 10^6 candidates (0.907) 302 -> 295 us, 0.95: 303 -> 300;
+// forced at 0.75-0.875 the split LOSES 2-10 us, hence the threshold; the same at two and three full rounds.
+#ifndef SDPCUT_BALANCED_TAIL
+#define SDPCUT_BALANCED_TAIL 1
+#endif
+static void set_balanced_tail(ScoreArgs &A, int grid)
+{
+    A.rr_end = A.n; A.tail_nhi = 0; A.tail_hi = 0; A.tail_lo = 0;
+    if (!SDPCUT_BALANCED_TAIL || A.strip != 64) return;
+    const int64_t W = (int64_t)grid * 4, round = W * 64;
+    const int64_t R = A.n / round, rem = A.n - R * round;
+    const int64_t tiles = (rem + 15) / 16;
+    if (R < 1 || 10 * rem < 9 * round) return;
+    const int64_t lo = tiles / W;      // 3 (a remainder of a whole round is R + 1 rounds)
+    A.rr_end = R * round;
+    A.tail_lo = (int32_t)lo;
+    A.tail_hi = (int32_t)lo + 1;
+    A.tail_nhi = (tiles - lo * W + 3) / 4 * 4;
+}
+
 template <int K>
 static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
                           const ScoreFuse *fuse, int64_t *strong_out, hipStream_t st = nullptr)
@@ -1235,6 +1284,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
             A.strip = 32;
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
+        set_balanced_tail(A, grid);
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
@@ -1308,6 +1358,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
             A.strip = 32;
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
+        set_balanced_tail(A, grid);
         blocks += grid;
         AA.k[i] = k;
         AA.bend[i] = (int32_t)blocks;
