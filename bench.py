@@ -452,8 +452,9 @@ class _StdoutToStderr(object):
 ISSUE_CYCLES_PER_CAND = {
     # (r4, Householder + Laguerre lambda_min) VALU instructions per launch, of which quarter-rate transcendentals, MFMAs:
     ("eig", 3): ((8.065 - 0.229) * 4 + 0.229 * 16, "profiles/r04_eig_k3_kernel_pmc.txt (8.065 M VALU of which 0.229 M v_rsq / v_rcp_f64; round 3, Jacobi: 18.67 M)"),
-    ("mfma", 3): ((71.465 - 0.995) * 4 + 0.995 * 16 + 5.4375 * 64, "profiles/r04_k3_score_kernel_pmc.txt (71.46 M VALU of which 0.995 M transcendental + 5.4375 M MFMA "
-                                                                   "per launch = 4574 + 348 per 64-candidate strip; round 3: 83.71 M VALU = 5357 per strip)"),
+    ("mfma", 3): ((72.312 - 1.015) * 4 + 1.015 * 16 + 5.4375 * 64, "profiles/r04_k3_score_kernel_pmc.txt (72.31 M VALU of which 1.015 M transcendental + 5.4375 M MFMA "
+                                                                   "per launch = 4628 + 348 per 64 candidates, the partial strips of the balanced last round included; "
+                                                                   "round 3: 83.71 M VALU = 5357 per strip)"),
 }
 SIMDS, CLOCK_GHZ = 1024, 2.4
 
