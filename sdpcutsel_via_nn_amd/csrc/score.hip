@@ -1236,6 +1236,9 @@ static bool net_shape_ok(const sdpcut_ctx *h, int K, uint32_t flags)
 #ifndef SDPCUT_BALANCED_TAIL
 #define SDPCUT_BALANCED_TAIL 1
 #endif
+#ifndef SDPCUT_BALANCED_TAIL_MIN_FILL_PCT
+#define SDPCUT_BALANCED_TAIL_MIN_FILL_PCT 90
+#endif
 static void set_balanced_tail(ScoreArgs &A, int grid)
 {
     A.rr_end = A.n; A.tail_nhi = 0; A.tail_hi = 0; A.tail_lo = 0;
@@ -1243,7 +1246,7 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
     const int64_t W = (int64_t)grid * 4, round = W * 64;
     const int64_t R = A.n / round, rem = A.n - R * round;
     const int64_t tiles = (rem + 15) / 16;
-    if (R < 1 || 10 * rem < 9 * round) return;
+    if (R < 1 || 100 * rem < SDPCUT_BALANCED_TAIL_MIN_FILL_PCT * round) return;
     const int64_t lo = tiles / W;      // 3 (a remainder of a whole round is R + 1 rounds)
     A.rr_end = R * round;
     A.tail_lo = (int32_t)lo;
