@@ -342,3 +342,37 @@ def test_short_list_tie_group_beyond_the_sort_buffers(oracle, count):
         assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("k,count", [(3, 1000003), (4, 1010101)])
+def test_balanced_last_round_of_the_scoring_kernel(k, count):
+    """Lists whose last round-robin round is at least 90 % full have it dealt out evenly in column tiles (score.hip
+    set_balanced_tail): strips of three tiles, a last strip that ends inside a tile.  Every candidate is scored once, and its
+    scores are bit for bit what the same candidate gets in a list that is split differently (its last 300 001 candidates alone:
+    whole strips) -- a score depends on the candidate, never on where the work split puts it."""
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    wl = synthetic.make_workload(nb_vars=100, k=k, count=count, seed=3)
+    sc = _capi.Scorer(0)
+    try:
+        sc.set_network(k, *networks.load_network(k))
+        sc.set_instance(100, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        sc.set_point(wl["vars_values"])
+        sc.score(_capi.EIG | _capi.NN)
+        eig, obj = (a.copy() for a in sc.get_scores())
+        assert np.isfinite(eig).all() and np.isfinite(obj).all()
+        sc.set_option(_capi.OPT_KERNEL, _capi.KERNEL_VALU)      # reference operation order, its own work split
+        sc.set_point(wl["vars_values"])
+        sc.score(_capi.EIG | _capi.NN)
+        eig_v, obj_v = sc.get_scores()
+        assert np.array_equal(eig, eig_v)
+        assert np.abs(obj - obj_v).max() <= 1e-9 * max(1.0, np.abs(obj_v).max())
+        sc.set_option(_capi.OPT_KERNEL, _capi.KERNEL_MFMA)
+        tail = slice(count - 300001, count)
+        sc.set_candidates(wl["set_inds"][tail], wl["ks"][tail])
+        sc.set_point(wl["vars_values"])
+        sc.score(_capi.EIG | _capi.NN)
+        eig_t, obj_t = sc.get_scores()
+        assert np.array_equal(eig_t, eig[tail]) and np.array_equal(obj_t, obj[tail])
+    finally:
+        sc.close()
