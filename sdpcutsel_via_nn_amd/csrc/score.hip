@@ -633,11 +633,16 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
 #ifndef SDPCUT_XPREFETCH_MAXK
 #define SDPCUT_XPREFETCH_MAXK 2
 #endif
+// (r4) ... and for K = 5 again: with lambda_min by lmin.h instead of the 6x6 Jacobi the 5-variable kernel has the registers the
+// prefetch needs -- 584 -> 566 us on 1e6 candidates (-3 %); K = 3 still loses 0.6 %, K = 4 is indifferent.
+#ifndef SDPCUT_XPREFETCH_MINK
+#define SDPCUT_XPREFETCH_MINK 5
+#endif
 #ifndef SDPCUT_RING_DEPTH
 #define SDPCUT_RING_DEPTH 4
 #endif
         constexpr int RD = SDPCUT_RING_DEPTH;
-        constexpr bool XP = SDPCUT_XPREFETCH && K <= SDPCUT_XPREFETCH_MAXK;
+        constexpr bool XP = SDPCUT_XPREFETCH && (K <= SDPCUT_XPREFETCH_MAXK || K >= SDPCUT_XPREFETCH_MINK);
         double a_in[S0];              // input-layer fragments of the tile about to run
         double pre[RD];               // head of the next hidden layer's fragment stream
         if constexpr (XP) {
