@@ -423,7 +423,9 @@ class Scorer(object):
                 v_coef = np.frombuffer(buf, dtype=np.float64, count=c * ld, offset=o).reshape(c, ld); o += 8 * c * ld
                 v_ks = np.frombuffer(buf, dtype=np.int32, count=c, offset=o)
                 self._round_views, self._round_view_key = (v_idx, v_sc, v_lam, v_rhs, v_coef, v_ks), key
-            idx, sc, lam, rhs, coef, ks = (a[:w] for a in self._round_views)
+            if getattr(self, "_round_slices_w", None) != (key, w):      # (the head usually has the same length round after round)
+                self._round_slices, self._round_slices_w = tuple(a[:w] for a in self._round_views), (key, w)
+            idx, sc, lam, rhs, coef, ks = self._round_slices
             if copy:
                 idx, sc, lam, rhs, coef, ks = (a.copy() for a in (idx, sc, lam, rhs, coef, ks))
         else:
