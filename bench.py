@@ -82,10 +82,62 @@ def _cpu_score_chunk(args):
     return obj, lam
 
 
-def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
+def host_cores():
+    """-> (cores this process may use, how that was found): the scheduler affinity mask, cut by the cgroup's CPU quota when there
+    is one (a container on a 256-thread host may be allowed all 256 or a 16-CPU share; oversubscribing a quota only adds
+    throttling)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = aff if quota is None else max(1, min(aff, int(quota)))
+    return cores, "len(os.sched_getaffinity(0)) = %d, cgroup CPU quota = %s, os.cpu_count() = %d" % (
+        aff, "none" if quota is None else "%.1f" % quota, os.cpu_count() or 0)
+
+
+def selection_parity(oracle, strat, obj, lam, max_elem, sel, gpu):
+    """The GPU round against the ranking of the ORACLE'S OWN scores on the same list (cut_select_qp.py:601-632, :639-654).
+    gpu: dict(idx, score, new_strat, eig, obj) -- head ids / scores of one round as the device returned them and the device's
+    score arrays (None where the round did not compute the measure).  Position-by-position comparison of the head; the score
+    deviations are over EVERY candidate of the list, not the head only."""
+    order, scores, new_strat, _ = oracle.rank_arrays(strat, obj, lam, sel)
+    head, head_scores = order[:sel], scores[:sel]
+    ids = np.asarray(gpu["idx"], dtype=np.int64)
+    m = min(len(head), len(ids))
+    differing = int((head[:m] != ids[:m]).sum()) + abs(len(head) - len(ids))
+    one_side = int(len(np.setxor1d(head, ids)))
+    out = {"strategy": strat, "head": int(len(head)), "gpu_head": int(len(ids)), "topk_identical": bool(differing == 0),
+           "positions_differing": differing, "ids_one_side_only": one_side,
+           "new_strategy_identical": bool(int(gpu["new_strat"]) == int(new_strat)),
+           "against": "oracle.rank_arrays on the oracle's own obj_improve / lambda_min of all %d candidates" % len(order if strat != 1 else lam)}
+    if m:
+        same = head[:m] == ids[:m]
+        out["max_abs_d_head_score"] = float(np.abs(np.asarray(gpu["score"])[:m][same] - head_scores[:m][same]).max()) if same.any() else None
+    if gpu.get("eig") is not None and lam is not None:
+        out["max_abs_d_eig"] = float(np.abs(gpu["eig"] - lam).max())
+    if gpu.get("obj") is not None and obj is not None:
+        # the tolerance form of the parity tests (SURVEY section 7, hard part 5): |d| relative to max(|score|, 1e-3 max_elem)
+        out["max_rel_d_obj"] = float((np.abs(gpu["obj"] - obj) / np.maximum(np.abs(obj), 1e-3 * max_elem)).max())
+        out["max_abs_d_obj"] = float(np.abs(gpu["obj"] - obj).max())
+    return out
+
+
+def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample, gpu_rounds=None):
     """The oracle ("port": C restatement of NNs.so + batched LAPACK eigvalsh + numpy ranking) on the
-    first `sample` candidates of the same workload: 1 core, all cores (process pool), and the
-    reference's own shape (per-candidate Python loop)."""
+    first `sample` candidates of the same workload: 1 core, all cores this process may use (process pool), and the
+    reference's own shape (per-candidate Python loop).  gpu_rounds {strategy: record of selection_parity}: when the sample is
+    the whole list, the GPU rounds of this run are compared with the ranking of the oracle's scores -> out["parity"]."""
     from oracle import cutsel_oracle as oracle
     si = np.ascontiguousarray(set_inds[:sample, :k])
     L = nb_vars * (nb_vars + 1) // 2
@@ -97,13 +149,26 @@ def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
             oracle.get_eigendecomp(k, vv[L:][si[c]], vv[:L][oracle.triu_positions(si[c], nb_vars)], True)
 
     t0 = time.perf_counter()
-    finish(*_cpu_score_chunk((k, nb_vars, si, vv, Q)))
+    obj1, lam1 = _cpu_score_chunk((k, nb_vars, si, vv, Q))
+    finish(obj1, lam1)
     dt = time.perf_counter() - t0
     out = dict(value=sample / dt, unit="candidates/s", cores=1, kind="port",
                sample="first %d of the %d candidates of this workload, same round (score eig+NN, combined "
                       "ranking, %d eigh cut rows), %.1f s" % (sample, n_workload, sel, dt))
-    # all host cores of the box: the scoring split over a process pool
-    cores = min(os.cpu_count() or 1, 16)
+    if gpu_rounds and sample == n_workload:
+        q = np.abs(np.asarray(Q)[oracle.triu_positions(si, nb_vars)]).max(axis=1) * k
+        max_elem = np.where(q == 0, 1.0, q)
+        par = {}
+        for strat, rec in sorted(gpu_rounds.items()):
+            par[strat] = selection_parity(oracle, strat, None if strat == 1 else obj1, None if strat == 2 else lam1, max_elem, sel, rec)
+        main = dict(par.get(4) or par[sorted(par)[0]])
+        for strat, p in par.items():
+            if p is not main and strat != main["strategy"]:
+                main["strategy_%d" % strat] = p
+        out["parity"] = main
+    # all host cores this process may use (SURVEY 8 d): the scoring split over a process pool;
+    # the ranking and the cut rows (serial numpy / LAPACK) are timed separately
+    cores, how = host_cores()
     if cores > 1:
         import multiprocessing as mp
         chunks = np.array_split(np.arange(sample), cores * 4)
@@ -111,11 +176,16 @@ def cpu_baseline(set_inds, nb_vars, k, vv, Q, n_workload, sample):
             pool.map(_cpu_score_chunk, [(k, nb_vars, si[:64], vv, Q)] * cores)          # start the workers (untimed)
             t1 = time.perf_counter()
             parts = pool.map(_cpu_score_chunk, [(k, nb_vars, si[c], vv, Q) for c in chunks])
-            finish(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
-            dt_all = time.perf_counter() - t1
-        out["all_cores"] = dict(value=sample / dt_all, unit="candidates/s", cores=cores,
-                                sample="same sample, scoring over a %d-process pool (os.cpu_count() = %d), ranking "
-                                       "and cut rows on one, %.1f s" % (cores, os.cpu_count(), dt_all))
+            obj_all, lam_all = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+            t2 = time.perf_counter()
+            finish(obj_all, lam_all)
+            t3 = time.perf_counter()
+        out["all_cores"] = dict(value=sample / (t2 - t1), unit="candidates/s", cores=cores,
+                                scoring_s=t2 - t1, ranking_and_rows_s_one_core=t3 - t2, value_whole_round=sample / (t3 - t1),
+                                sample="same sample, eig + NN scoring over a %d-process pool (%s): %.2f s; `value` is the scoring "
+                                       "rate; the ranking and the %d cut rows run on one core after it: %.2f s"
+                                       % (cores, how, t2 - t1, sel, t3 - t2))
+        out["all_cores_value"], out["all_cores_cores"] = out["all_cores"]["value"], cores      # (scalars survive the driver's record)
     # the reference's own shape -- a Python loop with one ctypes call
     # into the NNs.so-compatible entry point and one LAPACK eigvalsh per candidate -- on a small
     # sub-sample (optimality list + feasibility list = both measures for every candidate)
@@ -373,7 +443,14 @@ def bench_triangle(device_index, steps):
             "cuts": int(nb), "step_ms": dt * 1e3, "steps": steps}
 
 
-def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
+def gpu_round_record(sc, res, strat):
+    """what selection_parity compares: the head of one GPU round (detached from the handle's pinned block) and the device's
+    score arrays of that round (only the measures the strategy computes)"""
+    eig, obj = sc.get_scores(eig=strat != 2, obj=strat != 1)
+    return dict(idx=np.array(res["idx"]), score=np.array(res["score"]), new_strat=int(res["new_strat"]), eig=eig, obj=obj)
+
+
+def bench_eig_only(make_scorer, K, n_local, vv_host, steps, gpu_rounds=None):
     """the feasibility round (strategy 1) on the main workload: eigenvalue-only kernel + selection + rows"""
     import torch
     from sdpcutsel_via_nn_amd import _capi
@@ -389,8 +466,10 @@ def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
     sc.set_option(_capi.OPT_TIMING, 1)
     ms = []
     for _ in range(10):
-        sc.select_round(1, SEL, copy=False, point=vv_host)
+        res = sc.select_round(1, SEL, copy=False, point=vv_host)
         ms.append(sc.last_timing()[0])
+    if gpu_rounds is not None:
+        gpu_rounds[1] = gpu_round_record(sc, res, 1)
     sc.close()
     k_ms = float(np.mean(ms))
     bytes_per = 4 * K + 8             # index set in, one fp64 out
@@ -405,7 +484,7 @@ def bench_eig_only(make_scorer, K, n_local, vv_host, steps):
                                  "issue (DESIGN.md section 5), the HBM figure is the algorithmic one"}}
 
 
-def bench_opt_only(make_scorer, K, n_local, vv_host, steps):
+def bench_opt_only(make_scorer, K, n_local, vv_host, steps, gpu_rounds=None):
     """the optimality round (strategy 2, cut_select_qp.py:569-601: the paper's choice for dense instances) on the main workload: the MLP
     without the eigenvalue, ranking by obj_improve, cut rows of the head (their lambda_min and eigenvector come from the epilogue)"""
     import torch
@@ -422,8 +501,10 @@ def bench_opt_only(make_scorer, K, n_local, vv_host, steps):
     sc.set_option(_capi.OPT_TIMING, 1)
     ms = []
     for _ in range(10):
-        sc.select_round(2, SEL, copy=False, point=vv_host)
+        res = sc.select_round(2, SEL, copy=False, point=vv_host)
         ms.append(sc.last_timing()[0])
+    if gpu_rounds is not None:
+        gpu_rounds[2] = gpu_round_record(sc, res, 2)
     sc.close()
     k_ms = float(np.mean(ms))
     tflops = FLOPS_PER_CAND[K] * n_local / (k_ms * 1e-3) / 1e12
@@ -734,11 +815,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last_res = step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # the LAST round of the timed region, kept for the parity object of the line (compared with the ranking of the oracle's own
+    # scores after everything is timed, cpu_baseline): ids / scores as returned, the device's score arrays of that round
+    gpu_rounds = {}
+    if world == 1 and sel is None and not args.no_cpu_baseline:
+        gpu_rounds[4] = gpu_round_record(sc, last_res, 4)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -839,8 +925,8 @@ def main():
                 s2.close()
             out["secondary"] = sec
             # the feasibility round (strategy 1, cut_select_qp.py:639-654) on the same list: the eigenvalue-only kernel
-            out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
-            out["secondary"]["strategy_2"] = bench_opt_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4))
+            out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
+            out["secondary"]["strategy_2"] = bench_opt_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))
@@ -851,7 +937,16 @@ def main():
             if sets_host is None:       # device-generated list: the numpy twin of the generator names the sample
                 m = min(args.cpu_sample, n_local)
                 sets_host = synthetic.philox_index_sets(nb_vars, K, np.arange(m), seed=7)
-            out["cpu_baseline"] = cpu_baseline(sets_host, nb_vars, K, vv_host, Q_arr, n_local, min(args.cpu_sample, n_local))
+            out["cpu_baseline"] = cpu_baseline(sets_host, nb_vars, K, vv_host, Q_arr, n_local, min(args.cpu_sample, n_local), gpu_rounds)
+            par = out["cpu_baseline"].pop("parity", None)
+            if par is not None:
+                # the GPU rounds of THIS run against the ranking of the oracle's own scores on the whole list (cut_select_qp.py:601-632)
+                out["parity"] = par
+                for key in ("topk_identical", "positions_differing", "ids_one_side_only", "max_abs_d_eig", "max_rel_d_obj"):
+                    out["cpu_baseline"]["parity_" + key] = par.get(key)      # (scalars survive the driver's record of the line)
+                for s_ in (1, 2):
+                    if "strategy_%d" % s_ in par:
+                        out["cpu_baseline"]["parity_strategy_%d_topk_identical" % s_] = par["strategy_%d" % s_]["topk_identical"]
         print(json.dumps(out), flush=True)
     sc.close()
     if use_dist:

@@ -46,14 +46,129 @@ def _trajectories():
     return sorted(glob.glob(os.path.join(GOLDEN, "rounds_*.npz")))
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Where the replay may differ from the reference's recorded ORDER, and what the test proves about it AT RUN TIME (VERDICT r4
+# item 2).  199 recorded rounds; everywhere else the head must be the reference's, position by position.
+#
+# A pair of candidates (a, b) is INVERTED when the reference's list and ours put them in opposite orders (a candidate that only
+# one side selected counts as ranked behind the other side's whole head).  For every inverted pair the test computes
+#   * the TRUE difference of the two scores -- feasibility measure: the EXACT smallest eigenvalues (tests/exact_eig.py: integer
+#     characteristic polynomial, 80-digit root); optimality measure: the reference's own obj_improve (oracle = NNs.so bit for bit);
+#   * the measured error of each side on each of the two candidates -- |reference's recorded score - true|, |device score - true|
+#     (a candidate outside the reference's recorded head has no recorded score: this box's LAPACK stands in for it);
+# and asserts  |true(a) - true(b)| <= err_ref(a) + err_ref(b) + err_dev(a) + err_dev(b),  every single error inside the accuracy
+# the parity tests hold everywhere (eigenvalues 2e-15 -- LAPACK's own distance from the exact value reaches 8e-16 on these
+# matrices --, obj_improve 1e-9 relative).  I.e. the two solvers' measured errors ON THESE TWO MATRICES are what inverts the
+# pair, not an ordering rule.  At generic LP points the inverted pairs are additionally PINNED by id: a third pair fails.
+ADMITTED_PAIRS = {
+    # (trajectory, round): inverted pairs (ids in the reference's order)
+    ("rounds_spar125_075_1_d4_s4", 5): [(806014, 803286)],       # permuted copies of ONE matrix: exact eigenvalues equal, LAPACK puts them 2.8e-16 apart
+    ("rounds_spar125_075_2_d3_s4", 2): None,                      # filled from the diagnostic run below
+    ("rounds_spar125_075_2_d3_s4", 18): None,
+}
+# the McCormick vertex and the two LPs after it under PURE feasibility (x = 0.5, X in {0, 0.5}: 2 / 245 / thousands of distinct
+# eigenvalues in a head of 5000): exact tie groups, whose members LAPACK's rounding orders -- too many pairs to name, every
+# inverted pair is still proven as above (stated deviation 1)
+STRUCTURED_ROUNDS = {("rounds_spar080_075_1_d4_s1", 1), ("rounds_spar080_075_1_d4_s1", 2), ("rounds_spar080_075_1_d4_s1", 3)}
+EIG_ERR_MAX = 2e-15
+OBJ_ERR_REL = 1e-9
+
+
+def _append_report(lines):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "r05_config3_replay.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def _dd(dec):
+    """80-digit Decimal -> (hi, lo) doubles"""
+    from decimal import Decimal
+    hi = float(dec)
+    return hi, float(dec - Decimal(hi))
+
+
+def _explain_inversions(oracle, sc, inst, g, r, strat, res, ref_ids, ref_score):
+    """-> (inverted pairs [(a, b)] or None when there are more than 1000, report lines); asserts the per-pair criterion of the
+    comment above"""
+    import exact_eig
+    n, L = inst["nb_vars"], inst["nb_lifted"]
+    vv = np.asarray(g["r%02d_vars" % r], dtype=np.float64)
+    ours = res["idx"].astype(np.int64)
+    w = ref_ids.shape[0]
+    diff = np.flatnonzero(ours != ref_ids)
+    # everybody between the first and the last differing position: a candidate that kept its place can still be inverted
+    # against one that moved across it
+    span = slice(int(diff[0]), int(diff[-1]) + 1)
+    involved = np.unique(np.concatenate([ours[span], ref_ids[span]]))
+    only_ref, only_ours = np.setdiff1d(ref_ids, ours), np.setdiff1d(ours, ref_ids)
+    # rank of every involved candidate on both sides (w = behind the whole head)
+    pos_ref = {int(c): i for i, c in enumerate(ref_ids)}
+    pos_our = {int(c): i for i, c in enumerate(ours)}
+    pr = np.array([pos_ref.get(int(c), w) for c in involved])
+    po = np.array([pos_our.get(int(c), w) for c in involved])
+    eig_dev, obj_dev = sc.get_scores(eig=strat != 2, obj=strat != 1)      # what the round just run scored
+    S, ks = sc.get_candidates(involved)
+    m = involved.shape[0]
+    true_hi, true_lo, e_ref, e_dev, kind = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m), []
+    for i, c in enumerate(involved):
+        k = int(ks[i])
+        si = S[i, :k]
+        x, X = vv[L:][si], vv[:L][oracle.triu_positions(si, n)]
+        recorded = ref_score[pos_ref[int(c)]] if int(c) in pos_ref else None
+        lam_here = float(oracle.get_eigendecomp(k, x, X, False)[0])
+        lam_dev = float(eig_dev[c]) if eig_dev is not None else None
+        is_eig = strat == 1 or (strat == 4 and recorded is not None and abs(recorded + lam_dev) <= 1e-12)
+        if is_eig:      # the score is -lambda_min
+            t = exact_eig.exact_lambda_min_of(k, x, X, lam_here)
+            hi, lo = _dd(-t)
+            from decimal import Decimal
+            e_ref[i] = abs(float(Decimal(float(recorded if recorded is not None else -lam_here)) - (-t)))
+            e_dev[i] = abs(float(Decimal(-lam_dev) - (-t)))
+            assert e_ref[i] <= EIG_ERR_MAX and e_dev[i] <= EIG_ERR_MAX, (r, int(c), e_ref[i], e_dev[i])
+        else:           # obj_improve (+- BIG_M): the truth is the reference's own arithmetic
+            o_ref = float(oracle.opt_score_batch(k, si[None, :], n, vv, inst["Q_arr"])[0])
+            off = 0.0 if recorded is None else round((recorded - o_ref) / 1000.0) * 1000.0
+            hi, lo = o_ref + off, 0.0
+            e_ref[i] = 0.0 if recorded is None else abs(recorded - (o_ref + off))      # the rounding of obj_improve + 1000
+            e_dev[i] = abs(float(obj_dev[c]) - o_ref)
+            tol = OBJ_ERR_REL * max(abs(o_ref), 1e-3 * k * max(1.0, float(np.abs(inst["Q_arr"][oracle.triu_positions(si, n)]).max())))
+            assert e_dev[i] <= tol and e_ref[i] <= 2.3e-13, (r, int(c), e_dev[i], e_ref[i])
+        true_hi[i], true_lo[i] = hi, lo
+        kind.append("eig" if is_eig else "opt")
+    # inverted pairs: ordered one way by the reference, the other way by us (both outside one head: no statement)
+    inv = ((pr[:, None] < pr[None, :]) & (po[:, None] > po[None, :]))
+    ia, ib = np.nonzero(inv)
+    d_true = np.abs((true_hi[ia] - true_hi[ib]) + (true_lo[ia] - true_lo[ib]))
+    budget = e_ref[ia] + e_ref[ib] + e_dev[ia] + e_dev[ib]
+    bad = d_true > budget + 1e-30
+    assert not bad.any(), (r, [(int(involved[a]), int(involved[b]), float(d), float(q)) for a, b, d, q in
+                               zip(ia[bad][:5], ib[bad][:5], d_true[bad][:5], budget[bad][:5])])
+    pairs = [(int(involved[a]), int(involved[b])) for a, b in zip(ia, ib)] if ia.size <= 1000 else None
+    lines = ["    round %d: %d positions differ, %d / %d ids on one side only, %d inverted pairs, largest true difference %.3e "
+             "(its error budget %.3e), kinds %s" % (r, diff.size, only_ref.size, only_ours.size, ia.size,
+                                                    d_true.max() if d_true.size else 0.0,
+                                                    budget[np.argmax(d_true)] if d_true.size else 0.0, sorted(set(kind)))]
+    for d, i, j in list(zip(d_true, ia, ib))[:12]:
+        lines.append("        pair (%d, %d): true difference %.3e, errors reference %.2e + %.2e, device %.2e + %.2e"
+                     % (int(involved[i]), int(involved[j]), d, e_ref[i], e_ref[j], e_dev[i], e_dev[j]))
+    return pairs, lines
+
+
 @pytest.mark.parametrize("path", _trajectories(), ids=[os.path.basename(p)[:-4] for p in _trajectories()])
-def test_replay_of_the_reference_trajectory(path):
+def test_replay_of_the_reference_trajectory(path, oracle):
     """Every round the reference ran (its LP point, its rank-list head, its strategy switch, its number
     of cuts): same selection from the library.  Identical selections make the next LP -- and hence the
-    whole trajectory -- identical, so this is configs[2] end to end, minus the LP solver."""
+    whole trajectory -- identical, so this is configs[2] end to end, minus the LP solver.
+
+    Ten recorded trajectories, 199 rounds: spar125-075-{1,2,3} dim 4 combined (20 rounds each, 1.6-1.7e6 candidates),
+    spar125-050-1 / spar100-050-1 / spar070-050-1 dim 5 combined (mixed 2..5-variable covers), spar125-075-1 dim 3 and
+    spar090-075-1 dim 4 optimality, spar125-075-2 dim 3 combined, spar080-075-1 dim 4 feasibility from the first round.
+    EVERY position of EVERY head is the reference's, except in the rounds named by ADMITTED_PAIRS / STRUCTURED_ROUNDS, where each
+    inverted pair is proven at run time to lie inside the two solvers' measured errors on those two matrices."""
     import sdpcutsel_via_nn_amd as pkg
-    from sdpcutsel_via_nn_amd import _capi
     g = np.load(path)
+    base = os.path.basename(path)[:-4]
     name, dim, sel = str(g["name"]), int(g["dim"]), int(g["sel_size"])
     inst = _instance(name)
     sc = pkg.Scorer(0)
@@ -64,7 +179,7 @@ def test_replay_of_the_reference_trajectory(path):
         assert N == int(g["nb_subproblems"])
         rounds = int(g["rounds_done"])
         assert rounds >= 3
-        report, differing_rounds = [], []
+        report, seen = [], set()
         for r in range(1, rounds + 1):
             p = "r%02d_" % r
             strat = int(g[p + "strat"])
@@ -78,58 +193,28 @@ def test_replay_of_the_reference_trajectory(path):
             assert np.all(np.abs(res["score"] - ref_score) <= tol), (r, np.abs(res["score"] - ref_score).max())
             same = res["idx"] == ref_ids
             n_set = int(np.setdiff1d(res["idx"], ref_ids).size)
-            # The reference's ORDER, position by position (profiles/r04_trajectory_replay.txt).  Ten recorded trajectories, 199
-            # rounds: spar125-075-{1,2,3} dim 4 combined (20 rounds each, 1.6-1.7e6 candidates), spar125-050-1 / spar100-050-1 /
-            # spar070-050-1 dim 5 combined (mixed 2..5-variable covers), spar125-075-1 dim 3 and spar090-075-1 dim 4 optimality,
-            # spar125-075-2 dim 3 combined, spar080-075-1 dim 4 feasibility from the first round.
-            #
-            # A position may differ ONLY inside a run of reference scores that the reference's own arithmetic does not separate:
-            #  * eigenvalue scores (-lambda_min) equal to NOISE = 1e-15 absolute.  LAPACK's distance from the EXACT eigenvalue is
-            #    1e-16 on average and up to 8e-16 on these very matrices (tools/lmin_truth.py: rational characteristic polynomial,
-            #    80-digit root), so is that of csrc/lmin.h (r4); the reference run on another CPU orders such pairs differently
-            #    (profiles/r04_lambda_min_noise_floor.txt: the GPU box's LAPACK against the build container's).  Round 5 of
-            #    spar125-075-1 dim 4 holds one such pair -- two candidates whose exact eigenvalues are EQUAL (permuted copies of
-            #    one matrix), 2.8e-16 apart in the reference's list;
-            #  * scores equal to 1e-12 relative (obj_improve + 1000 swallows the low bits of obj_improve, cut_select_qp.py:611:
-            #    round 2 of the dim-3 trajectory of spar125-075-2);
-            #  * the exact ties of a structured vertex (the pure-feasibility trajectory, rounds 1-3, below).
-            # Either way the run holds the SAME ids on both sides unless it reaches the end of the head.
+            extra = []
             if not same.all():
-                base = os.path.basename(path)
-                NOISE = 1e-15
-                brk = np.flatnonzero(np.abs(np.diff(ref_score)) > np.maximum(1e-12 * np.abs(ref_score[:-1]), NOISE))
-                starts, stops = np.concatenate([[0], brk + 1]), np.concatenate([brk + 1, [w]])
-                run_of = np.repeat(np.arange(starts.size), stops - starts)
-                for k in np.unique(run_of[~same]):
-                    lo, hi = int(starts[k]), int(stops[k])
-                    assert hi - lo > 1, (r, lo, ref_score[max(lo - 1, 0):hi + 1].tolist())
-                    if hi < w:
-                        assert np.array_equal(np.sort(res["idx"][lo:hi]), np.sort(ref_ids[lo:hi])), (r, lo, hi)
-                if not (base.endswith("_s1.npz") and r <= 3):
-                    # generic LP points: a handful of neighbours at most, never another SET
-                    assert (~same).sum() <= 8 and n_set == 0, (r, np.flatnonzero(~same).tolist(), n_set)
+                key = (base, r)
+                assert key in ADMITTED_PAIRS or key in STRUCTURED_ROUNDS, \
+                    "%s round %d must reproduce the reference's head position by position: %d positions differ (%s)" % (
+                        base, r, int((~same).sum()), np.flatnonzero(~same)[:10].tolist())
+                pairs, extra = _explain_inversions(oracle, sc, inst, g, r, strat, res, ref_ids, ref_score)
+                _append_report(["%s round %d (strategy %d): inverted pairs %s" % (base, r, strat, pairs)] + extra)
+                if key in ADMITTED_PAIRS:
+                    assert n_set == 0, (r, n_set)
+                    want = ADMITTED_PAIRS[key]
+                    assert want is not None and pairs is not None and sorted(map(tuple, map(sorted, pairs))) == sorted(map(tuple, map(sorted, want))), (key, pairs)
                 else:
-                    # A trajectory that runs pure feasibility from the FIRST round starts at the McCormick vertex: round 1 of
-                    # spar080-075-1 has TWO distinct scores in its head of 5000, round 2 (the LP after 5000 cuts out of those
-                    # ties) 245, round 3 eight pairs of equal eigenvalues one ulp apart; from round 4 on every position is the
-                    # reference's.  The deviation DESIGN.md section 2 states for structured vertices, here measured along a
-                    # recorded trajectory: list lengths, scores (1.2e-15) and cut counts are the reference's in all 20 rounds.
-                    assert strat == 1, (r, strat, int((~same).sum()))
-                differing_rounds.append(r)
+                    assert strat == 1, (r, strat)
+                seen.add(key)
             nb_cuts = int((res["lam"] < -1e-15).sum())
             assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
             report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "
                           "ids selected by one side only %d, cuts %d" % (name, dim, r, strat, res["new_strat"], N, w,
                                                                         int((~same).sum()), n_set, nb_cuts))
-        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r04_config3_replay.txt"), "a") as f:
-            f.write("\n".join(report) + "\n")
-        # how many rounds may differ at all (inside the runs asserted above): the three structured rounds of the pure-feasibility
-        # trajectory, at most three rounds of the dim-3 trajectory of spar125-075-2, at most one anywhere else
-        base = os.path.basename(path)
-        allowed = 3 if (base.endswith("_s1.npz") or "075_2_d3" in base) else 1
-        assert len(differing_rounds) <= allowed, differing_rounds
+            report.extend(extra)
+        _append_report(report)
     finally:
         sc.close()
 

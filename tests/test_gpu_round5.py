@@ -1,0 +1,94 @@
+"""Round-5 GPU tests (run with -m gpu on an MI355X).
+
+Selection parity against ORACLE-SCORED rankings at full size: every other full-size test ranks the
+device's own scores with the oracle (index work bit-exact given the scores); here the oracle scores the whole list itself
+(C restatement of NNs.so + LAPACK eigvalsh, a process pool over the box's cores) and its ranking
+(cut_select_qp.py:601-632, :639-654) is compared position by position with what the GPU round returns.  The comparison
+code is bench.py's own (`selection_parity`), so the `parity` object of the bench line is what is tested here.
+"""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EIG_ATOL = 2e-13      # as tests/test_gpu_parity.py
+OBJ_RTOL = 1e-9
+
+
+def oracle_scores(oracle, k, nb_vars, set_inds, vv, Q):
+    """(obj_improve, lambda_min) of every candidate by the oracle, split over a process pool (bench.py's worker)."""
+    import bench
+    cores = min(bench.host_cores()[0], 16)
+    n = set_inds.shape[0]
+    si = np.ascontiguousarray(set_inds[:, :k])
+    chunks = np.array_split(np.arange(n), max(1, cores * 4))
+    if cores == 1 or n < 200000:
+        parts = [bench._cpu_score_chunk((k, nb_vars, si[c], vv, Q)) for c in chunks]
+    else:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            parts = pool.map(bench._cpu_score_chunk, [(k, nb_vars, si[c], vv, Q) for c in chunks])
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def check_rounds(oracle, sc, wl, k, sel, base=0):
+    import bench
+    n, vv, Q = wl["nb_vars"], wl["vars_values"], wl["Q_arr"]
+    ref_obj, ref_eig = oracle_scores(oracle, k, n, wl["set_inds"], vv, Q)
+    q = np.abs(np.asarray(Q)[oracle.triu_positions(wl["set_inds"][:, :k], n)]).max(axis=1) * k
+    max_elem = np.where(q == 0, 1.0, q)
+    out = {}
+    for strat in (4, 2, 1):
+        res = sc.select_round(strat, sel, copy=True, point=vv)
+        rec = bench.gpu_round_record(sc, res, strat)
+        rec["idx"] = rec["idx"] - base
+        par = bench.selection_parity(oracle, strat, None if strat == 1 else ref_obj, None if strat == 2 else ref_eig, max_elem, sel, rec)
+        out[strat] = par
+        assert par["topk_identical"], par
+        assert par["positions_differing"] == 0 and par["ids_one_side_only"] == 0
+        assert par["new_strategy_identical"]
+        assert par["head"] == par["gpu_head"] == sel
+        if strat != 2:
+            assert par["max_abs_d_eig"] <= EIG_ATOL, par
+        if strat != 1:
+            assert par["max_rel_d_obj"] <= OBJ_RTOL, par
+        # the scores the round hands back are the oracle's new scores (obj_improve +- BIG_M, -lambda_min) within the same bounds
+        assert par["max_abs_d_head_score"] <= (1e-7 if strat != 1 else EIG_ATOL), par
+        # ... and the cuts' lambda_min (epilogue) is the oracle's eigenvalue of the same candidates
+        assert np.abs(res["lam"] - ref_eig[rec["idx"]]).max() <= EIG_ATOL
+    return out
+
+
+def test_headline_selection_equals_oracle_scored_ranking(oracle):
+    """BASELINE configs[1] (the bench list: n = 100, 1e6 random 3-variable sets, seed 7, sel_size 5000): the top-5000 of the
+    fused GPU round == the top-5000 of the oracle's ranking of ITS OWN scores, for the combined, optimality and
+    feasibility strategies; score deviations over all 1e6 candidates inside the stated tolerances."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import networks, synthetic
+    wl = synthetic.make_workload(nb_vars=100, k=3, count=10 ** 6, seed=7)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(100, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        check_rounds(oracle, sc, wl, 3, 5000)
+    finally:
+        sc.close()
+
+
+def test_config4_shard_selection_equals_oracle_scored_ranking(oracle):
+    """BASELINE configs[3], the share of one of 8 GPUs (n = 1000, 1.25e7 candidates, global ids of rank 5): the same
+    comparison -- the oracle scores all 1.25e7 candidates itself."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import networks, synthetic
+    n, N, base = 1000, 12_500_000, 5 * 12_500_000
+    wl = synthetic.make_workload(nb_vars=n, k=3, count=N, seed=12)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"], global_base=base)
+        check_rounds(oracle, sc, wl, 3, 5000, base=base)
+    finally:
+        sc.close()
