@@ -566,16 +566,33 @@ def self_launch(n_ranks):
     collective."""
     import socket
     import subprocess
+    # A profiler's preload (rocprofv3: LD_PRELOAD / ROCP* variables) initialises the GPU in THIS process before main() runs, and
+    # starting the ranks from a process that holds a GPU is the exec this pool's machines refuse (ADVICE r4).  Profile one rank
+    # (`rocprofv3 ... -- python3 bench.py --gpus 1`) or put the profiler inside the launch (`torch.distributed.run ... rocprofv3`).
+    preload = [k for k in os.environ if k == "LD_PRELOAD" or k.startswith("ROCP") or k.startswith("ROCPROF")]
+    if preload:
+        sys.stderr.write("bench.py: refusing to self-launch %d ranks under a profiler / preload (%s): the parent must not have touched "
+                         "a GPU.  Profile a single rank, or launch with torch.distributed.run and profile inside it.\n"
+                         % (n_ranks, ", ".join(sorted(preload))))
+        return 2
     from sdpcutsel_via_nn_amd import build as hip_build
     hip_build.build(verbose=True)           # compile only: no dlopen, no GPU
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    # rendezvous port: a bound (never listening) SO_REUSEADDR socket keeps the number ours until the ranks are gone -- rank 0's
+    # store binds the same port with SO_REUSEADDR, which Linux allows next to a non-listening holder, while a stranger's plain
+    # bind() is refused (the bind-close-reuse of round 4 left a window, ADVICE r4)
+    holder = socket.socket()
+    holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    holder.bind(("127.0.0.1", 0))
+    port = holder.getsockname()[1]
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SDPCUT_BENCH_SELF_LAUNCHED="1")
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports only dmabuf IPC; with the runtime's default (legacy IPC
+        # handles) RCCL's intra-node transport and any device-tensor sharing between processes fail at set-up with
+        # `hipIpcGetMemHandle: invalid argument` (the pool's environment notes; the variable is already exported on its
+        # machines -- setdefault keeps whatever the caller's environment says, this only covers a scrubbed environment).
+        # It changes how buffers are SHARED between ranks, nothing a single rank computes.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
         # rank 0's stdout is read here (exactly one JSON line goes on); every other rank's stdout joins stderr
@@ -603,6 +620,7 @@ def self_launch(n_ranks):
                 p.kill()
             deadline = float("inf")
     reader.join(timeout=10)
+    holder.close()
     json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:
         if ln not in json_lines[-1:]:
@@ -666,8 +684,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        print("bench.py: --gpus %d differs from the launcher's WORLD_SIZE=%d; running with %d ranks" % (args.gpus, world, world),
-              file=sys.stderr)
+        # a SCALE line must mean what its --gpus says: refuse instead of running another size under that label
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if os.environ.get("SDPCUT_BENCH_LAUNCH_ONLY") == "1":
         # launcher rehearsal without a GPU (tests/test_bench_contract.py, CPU): rendezvous over gloo, one collective, one line
         if os.environ.get("SDPCUT_BENCH_FAIL_RANK") == str(rank):
@@ -817,6 +835,7 @@ def main():
     for _ in range(args.steps):
         last_res = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0      # this rank's K steps, before it waits for the others
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -825,9 +844,17 @@ def main():
     gpu_rounds = {}
     if world == 1 and sel is None and not args.no_cpu_baseline:
         gpu_rounds[4] = gpu_round_record(sc, last_res, 4)
+    rank_ms = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dev_t = device if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # stragglers: every rank's own time for its K steps, before it waits for the others (the line's value uses the MAX of the
+        # barrier-to-barrier time)
+        mine = torch.tensor([dt_own], dtype=torch.float64, device=dev_t)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev_t) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dt = float(t.item())
 
     phases = None
@@ -892,6 +919,9 @@ def main():
         if use_dist:
             out["config"]["collective_backend"] = backend
             out["config"]["rccl_ranks"] = dist.get_world_size() if backend == "nccl" else 0      # ranks of the RCCL communicator
+            out["ms_per_step_ranks"] = {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms,
+                                        "note": "each rank's own K steps before the closing barrier; ms_per_step is the barrier-to-barrier MAX"}
+            out["config"]["ms_per_step_rank_min"], out["config"]["ms_per_step_rank_max"] = min(rank_ms), max(rank_ms)
             out["config"]["launcher"] = "self (python bench.py --gpus N)" if os.environ.get("SDPCUT_BENCH_SELF_LAUNCHED") == "1" \
                 else "torch.distributed.run"
             out["config"]["parallelism"] = "candidate shards x%d, one all-gather of per-shard heads per round" % world
@@ -949,8 +979,16 @@ def main():
                         out["cpu_baseline"]["parity_strategy_%d_topk_identical" % s_] = par["strategy_%d" % s_]["topk_identical"]
         print(json.dumps(out), flush=True)
     sc.close()
+    bad_comm = False
     if use_dist:
+        # the multi-GPU line is a statement about RCCL over xGMI: a run whose ranks did not all join ONE RCCL communicator of
+        # --gpus ranks must not pass as one -- the line above is printed, the exit code says no (the one-GPU rehearsal forms,
+        # which say what they are in config.collective_backend / rccl_ranks, are exempt)
+        rehearsal = backend != "nccl" or os.environ.get("SDPCUT_BENCH_ONE_DEVICE") == "1" or solo_dist
+        bad_comm = not rehearsal and (dist.get_backend() != "nccl" or dist.get_world_size() != args.gpus)
         dist.destroy_process_group()
+    if bad_comm:
+        sys.exit("bench.py: the RCCL communicator has %d ranks, --gpus asked for %d" % (world, args.gpus))
 
 
 def main_c3(args):

@@ -29,6 +29,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares is ALL it exports (tests/test_host_cpu.py) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct sdpcut_ctx *sdpcut_handle;
 
@@ -458,30 +462,14 @@ int sdpcut_tri_separate(sdpcut_handle h, int64_t max_out, int64_t *entry_out, do
 int sdpcut_mfma_probe(sdpcut_handle h, const double *A, const double *B, double *C);
 
 /*
- * The reference's own FFI, kept so that its binding works on this library unchanged:
- *
- *     nn_library = ctypes.cdll.LoadLibrary(<this library instead of 'neural_nets/NNs.so'>)   cut_select_qp.py:297
- *     func_dim = getattr(nn_library, "neural_net_%dD" % d); func_dim.restype = c_double     :299-300
- *     input_arr = (c_double * (d (d+3) / 2))();  ...  nn(input_arr)                          :302, :579-582
- *     (also utilities.py:80-89, :157)
- *
- * X = [x_rho (d) | Q_slice (d(d+1)/2)], returns the raw network output.  One call = a batch of one
- * on a process-wide default handle (device SDPCUT_COMPAT_DEVICE, default 0) with the built-in
- * networks.  NNs_initialize / NNs_terminate (no-ops in NNs.so) create / destroy that handle; the
- * first neural_net_kD call creates it if needed.  Without a gfx950 device the functions report
- * once on stderr and return NaN -- there is no CPU fallback (SURVEY.md section 8 b lists "CPU twins of each"
- * entry point: deliberately absent).
- * (r4) BIT-IDENTICAL to NNs.so: the reference's summation order without contraction, and exp evaluated as the host libm evaluates it
- * (NNs.so imports exp from libm: glibc >= 2.28 e_exp.c, the -mfma variant -- csrc/libm_exp.h).  4096 of 4096 recorded outputs per
- * network agree to the last bit (profiles/r04_accuracy.txt); sdpcut_nn_batch is the same kernel on a batch.
+ * The reference's own FFI (neural_net_{2,3,4,5}D, NNs_initialize, NNs_terminate; cut_select_qp.py:297-303) is exported by the
+ * sibling library libsdpcut_nns.so -- include/sdpcut_nns.h -- which binds to this one privately (sdpcut_create,
+ * sdpcut_set_builtin_networks, sdpcut_nn_batch).  Until round 4 this library exported the six names itself.
  */
-double neural_net_2D(const double X[5]);
-double neural_net_3D(const double X[9]);
-double neural_net_4D(const double X[14]);
-double neural_net_5D(const double X[20]);
-void NNs_initialize(void);
-void NNs_terminate(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDPCUT_LIB") or os.path.join(HERE, "libsdpcut_hip.so")   # env: experiment builds
+# the reference's own FFI (six symbols of NNs.so) lives in a sibling library that binds to the one above privately
+NNS_LIB_PATH = os.path.join(HERE, "libsdpcut_nns.so")
 
 EIG, NN = 1, 2
 STRAT_FEAS, STRAT_OPT, STRAT_COMB = 1, 2, 4
@@ -87,7 +89,7 @@ SIGNATURES = {
     "sdpcut_enumerate_cover": [_c.c_int32, _c.POINTER(_c.c_uint8), _c.c_int32, _c.c_int64, _i32p, _i32p, _i64p],
 }
 _RESTYPES = {"sdpcut_last_error": _c.c_char_p}
-# the reference's own FFI (cut_select_qp.py:297-303), exported by the same library
+# the reference's own FFI (cut_select_qp.py:297-303): ALL that libsdpcut_nns.so exports (include/sdpcut_nns.h)
 COMPAT_SYMBOLS = ["neural_net_2D", "neural_net_3D", "neural_net_4D", "neural_net_5D", "NNs_initialize", "NNs_terminate"]
 
 _lib = None

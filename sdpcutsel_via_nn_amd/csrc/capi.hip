@@ -91,7 +91,7 @@ int alloc_candidates(sdpcut_ctx *h, int64_t N, const int64_t cnt[SDPCUT_MAX_K + 
         HIP_TRY(h, hipMalloc((void **)&b.d_orig, (size_t)cnt[k] * sizeof(int32_t)));
     }
     h->N = N;
-    return ensure_rank_ws(h, N);
+    return 0;      // (the ranking workspaces are allocated by whoever first needs them: ensure_key_ws / ensure_rank_ws)
 }
 
 extern "C" {
@@ -167,7 +167,9 @@ int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap,
     int rc;
     const int fast_mode = (h->scored & need) == 0 ? rank_fast_mode(h, strat, sel_size, cap, nullptr) : 0;
     const bool want_auto = allow_auto && strat == SDPCUT_STRAT_COMB;
-    const bool count_digit = h->fuse_keys && topk_fuse_ok(h, cap, strat == SDPCUT_STRAT_COMB);
+    // (the short-list predicate must be the one topk_select_enqueue will evaluate: it sees the tie-aware combined modes only when
+    // the regime is resolved on the device -- a combined round whose mode the HOST resolved runs as TK_MODE_STRONG)
+    const bool count_digit = h->fuse_keys && topk_fuse_ok(h, cap, want_auto);
     if (fast_mode && (want_auto || count_digit)) {
         void *ws = nullptr;
         rc = topk_begin(h, &ws, nullptr);

@@ -117,7 +117,8 @@ struct sdpcut_ctx {
     NetHost net[SDPCUT_MAX_K + 1];
 
     // ranking workspace (sized to N by ensure_rank_ws)
-    int64_t ws_n = 0;
+    int64_t ws_n = 0;              // entries the full-list arrays hold (ensure_rank_ws)
+    int64_t key_n = 0;             // entries d_key_a holds (ensure_key_ws)
     uint64_t *d_key_a = nullptr, *d_key_b = nullptr;
     uint32_t *d_val_a = nullptr, *d_val_b = nullptr;
     int32_t *d_flag = nullptr, *d_scan = nullptr;
@@ -214,6 +215,7 @@ int launch_mfma_probe(sdpcut_ctx *h, const double *d_A, const double *d_B, doubl
 
 // rank.hip
 int ensure_rank_ws(sdpcut_ctx *h, int64_t n);
+int ensure_key_ws(sdpcut_ctx *h, int64_t n);
 int rank_on_device(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t max_out, int64_t *d_idx_out,
                    double *d_score_out, int64_t *n_written, int64_t *n_total, int32_t *new_strat,
                    int64_t *counters, int64_t strong_hint = -1);

@@ -1,5 +1,18 @@
 // exp() as the HOST's libm computes it -- for the batch-of-one / explicit-batch twins of the reference's NNs.so call only
-// (nn_batch_kernel behind sdpcut_nn_batch and the six compat symbols), never for the scoring kernels.
+// (nn_batch_kernel behind sdpcut_nn_batch and the six symbols of libsdpcut_nns.so), never for the scoring kernels.
+//
+// Provenance / licence: the operation sequence and the polynomial constants below are those of the GNU C Library's
+// sysdeps/ieee754/dbl-64/e_exp.c (glibc 2.28+; derived from ARM Optimized Routines, Copyright (c) 2018 Arm Ltd and the FSF;
+// glibc is licensed LGPL-2.1-or-later, the ARM original MIT / Apache-2.0 WITH LLVM-exception).  Nothing here comes from the
+// reference repository.  The table is not copied: build.py recomputes 2^(i/128) in 60-digit decimals.
+//
+// What is claimed: bit-identity with a host whose libm is glibc >= 2.28 on an x86-64 CPU with FMA (the ifunc then
+// picks the -mfma build, whose contractions are the fma() calls below) -- the build container and the GPU boxes; a host
+// without FMA or with another libm runs NNs.so itself through other roundings, and tests/test_round4_cpu.py says so instead
+// of failing there.  Arguments with |x| >= 512 leave glibc's main path (its `specialcase`: scaled evaluation near overflow /
+// underflow) and take the device's exp() here; INSIDE tansig -- the only use, a = 2 / (1 + exp(-2n)) - 1 -- that cannot change a
+// bit: exp(x) >= 2^738 gives 2 / (1 + e) < 2^-737, so a = -1 exactly, and exp(x) <= 2^-738 gives 1 + e = 1, a = 1 exactly,
+// whatever the last bits of e are (inf and 0 included).
 //
 // NNs.so (MATLAB Coder) imports `exp` from libm; its outputs are therefore a function of glibc's algorithm:
 // sysdeps/ieee754/dbl-64/e_exp.c (glibc >= 2.28, from ARM's optimized routines), EXP_TABLE_BITS = 7, polynomial of order 5, and

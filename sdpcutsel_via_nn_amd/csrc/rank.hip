@@ -136,15 +136,36 @@ void free_rank_ws(sdpcut_ctx *h)
     hipFree(h->d_key_a); hipFree(h->d_key_b); hipFree(h->d_val_a); hipFree(h->d_val_b);
     hipFree(h->d_flag); hipFree(h->d_scan); hipFree(h->d_tmp);
     h->d_key_a = h->d_key_b = nullptr; h->d_val_a = h->d_val_b = nullptr;
-    h->d_flag = h->d_scan = nullptr; h->d_tmp = nullptr; h->tmp_bytes = 0; h->ws_n = 0;
+    h->d_flag = h->d_scan = nullptr; h->d_tmp = nullptr; h->tmp_bytes = 0; h->ws_n = 0; h->key_n = 0;
 }
 
+// the key array alone (8 B per candidate): all that the head selection (topk.hip) may need of this workspace -- a round whose score
+// kernels counted the leading digit does not even read it
+int ensure_key_ws(sdpcut_ctx *h, int64_t n)
+{
+    if (n <= h->key_n) return 0;
+    (void)hipFree(h->d_key_a);
+    h->d_key_a = nullptr;
+    h->key_n = 0;
+    HIP_TRY(h, hipMalloc((void **)&h->d_key_a, (size_t)(n < 1 ? 1 : n) * 8));
+    h->key_n = n;
+    return 0;
+}
+
+// the whole workspace of the FULL-LIST ranking (~50 B per candidate: two key and two payload arrays, flags, scan, rocPRIM's
+// temporary storage).  Allocated when a full list is first asked for -- sdpcut_rank / rank_device with max_out > 16 384, what the
+// reference's method returns (cut_select_qp.py:601, :653: the whole sorted list) and a caller reads beyond the head
+// (sdpcut_rank_fetch) -- never by a round of the cutting-plane loop, whose heads of <= 5000 come from the radix select (r5;
+// until r4 every candidate list allocated it up front).
 int ensure_rank_ws(sdpcut_ctx *h, int64_t n)
 {
+    int rc = ensure_key_ws(h, n);
+    if (rc) return rc;
     if (n <= h->ws_n) return 0;
-    free_rank_ws(h);
+    hipFree(h->d_key_b); hipFree(h->d_val_a); hipFree(h->d_val_b); hipFree(h->d_flag); hipFree(h->d_scan); hipFree(h->d_tmp);
+    h->d_key_b = nullptr; h->d_val_a = h->d_val_b = nullptr; h->d_flag = h->d_scan = nullptr; h->d_tmp = nullptr;
+    h->tmp_bytes = 0; h->ws_n = 0;
     const size_t nn = (size_t)(n < 1 ? 1 : n);
-    HIP_TRY(h, hipMalloc((void **)&h->d_key_a, nn * 8));
     HIP_TRY(h, hipMalloc((void **)&h->d_key_b, nn * 8));
     HIP_TRY(h, hipMalloc((void **)&h->d_val_a, nn * 8));   // 8 B/entry: also used as u64 by the merge
     HIP_TRY(h, hipMalloc((void **)&h->d_val_b, nn * 8));

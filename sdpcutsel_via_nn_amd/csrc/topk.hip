@@ -832,7 +832,7 @@ int topk_begin(sdpcut_ctx *h, void **ws_out, uint64_t **keys_out)
 {
     int rc = ensure_topk_ws(h);
     if (rc) return rc;
-    rc = ensure_rank_ws(h, h->N);
+    rc = ensure_key_ws(h, h->N);
     if (rc) return rc;
     if (h->topk_alt_clean && h->d_topk_ws_alt) {
         // the epilogue of the previous round zeroed the other workspace (stream-ordered): swap
@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void smallsel_resolve(uint32_t *hist, SmallSelState *
 }
 
 // SORT (heads of at most TK_TILE entries, the usual 5-10 % of a short list): the superset is at most one tile -- it stays in LDS,
-// the first four waves sort it (bitonic, (key desc, [obj_improve desc,] index asc): tk_tilesort_kernel's network) and emit the head.
+// the workgroup sorts it (all sixteen waves reach every barrier, r5; bitonic, (key desc, [obj_improve desc,] index asc): tk_tilesort_kernel's network) and emit the head.
 // The round's selection is ONE launch instead of three (tile sort and merge ranks have nothing left to do); an every-entry-visited
 // tie group of more than TK_SORTMAX entries is declared void like a group beyond the merge's LDS in the other variant.
 #define TK_SORTMAX 2048
@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void smallsel_sort(uint64_t *sk, uint32_t *si, int P,
 {
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int q = threadIdx.x; q < (P >> 1); q += 256) {
+            for (int q = threadIdx.x; q < (P >> 1); q += TK_SMALLSEL_THREADS) {
                 const int pos = 2 * q - (q & (stride - 1));
                 const int par = pos + stride;
                 const bool up = (pos & size) == 0;
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void smallsel_sort(uint64_t *sk, uint32_t *si, int P,
                     si[pos] = ib; si[par] = ia;
                 }
             }
-            __syncthreads();      // (the four waves that are left: the others have ended)
+            __syncthreads();      // (every wave of the workgroup reaches every barrier: P / 2 <= 1024 compare-exchanges, one per thread)
         }
     }
 }
@@ -1320,11 +1320,10 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
             while (P < M) P <<= 1;
             for (int j = M + t; j < P; j += NT) { sk[j] = ~0ull; si[j] = 0xffffffffu; }      // padding sorts last
             __syncthreads();
-            if (wave >= 4) return;      // (ended waves leave the workgroup's barriers)
             if (comball) smallsel_sort<true>(sk, si, P, obj);
             else smallsel_sort<false>(sk, si, P, obj);
             const double add = (auto_mode && comball) ? 0.0 : score_add;      // (device-resolved regime: BIG_M belongs to the strong class only)
-            for (int r = t; r < k_eff; r += 256) {
+            for (int r = t; r < k_eff; r += NT) {
                 idx_out[r] = base + (int64_t)si[r];
                 score_out[r] = score_of(~sk[r]) + add;
             }
@@ -1408,12 +1407,11 @@ __global__ __launch_bounds__(TK_SMALLSEL_THREADS) void tk_smallsel_kernel(int mo
         while (P < M) P <<= 1;
         for (int j = M + t; j < P; j += NT) { sk[j] = ~0ull; si[j] = 0xffffffffu; }
         __syncthreads();
-        if (wave >= 4) return;
         // (the every-entry-visited regime gets here only with a tie group that is wanted whole: its members still go by obj_improve)
         if (comball) smallsel_sort<true>(sk, si, P, obj);
         else smallsel_sort<false>(sk, si, P, obj);
         const double add = (auto_mode && comball) ? 0.0 : score_add;
-        for (int r = t; r < k_eff; r += 256) {
+        for (int r = t; r < k_eff; r += NT) {
             idx_out[r] = base + (int64_t)si[r];
             score_out[r] = score_of(~sk[r]) + add;
         }
@@ -1556,7 +1554,7 @@ int topk_select_enqueue(sdpcut_ctx *h, int mode, int64_t k, double score_add, in
 // idx_out = entry index, val_out = the key's low 63 bits as a double; cnt as in topk_select_on_device.
 int topk_select_keys_on_device(sdpcut_ctx *h, int64_t n, int64_t k, int64_t *d_idx_out, double *d_val_out, int64_t cnt[5])
 {
-    if (k < 1 || k > TK_MAXK || n < 1 || n > h->ws_n) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k / n out of range");
+    if (k < 1 || k > TK_MAXK || n < 1 || n > h->key_n) return sdpcut_fail(h, SDPCUT_EINVAL, "top-k select: k / n out of range");
     int rc = topk_begin(h, nullptr, nullptr);
     if (rc) return rc;
     TopkWs *ws = (TopkWs *)h->d_topk_ws;
@@ -1634,7 +1632,7 @@ int topk_tie_split(sdpcut_ctx *h, int64_t k, int64_t *d_idx_out, double *d_score
     const int64_t k_eff = c[3], need = st8.need, above = k_eff - need;
     if (c[4] != 2 || c[6] != TK_MODE_COMBALL || need < 1 || above < 0 || k_eff > k) return 1;
     const uint64_t T = st8.prefix;
-    int rc = ensure_rank_ws(h, n);
+    int rc = ensure_key_ws(h, n);
     if (rc) return rc;
     const int64_t nb = (n + TK_THREADS - 1) / TK_THREADS;
     const int grid = (int)(nb < 4096 ? nb : 4096);

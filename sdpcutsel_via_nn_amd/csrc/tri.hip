@@ -81,7 +81,7 @@ int tri_separate(sdpcut_ctx *h, int64_t max_out, int64_t *d_entry_out, double *d
     int64_t cnt[5] = {0, 0, 0, 0, 0};
     if (max_out > 16384) return sdpcut_fail(h, SDPCUT_EINVAL, "tri_separate: at most 16384 entries (the reference takes <= 10000)");
     if (E > 0) {
-        int rc = ensure_rank_ws(h, E);
+        int rc = ensure_rank_ws(h, E > h->N ? E : h->N);      // (the selection below sizes the key array for the candidate list as well: it must not move)
         if (rc) return rc;
         h->last_total = -1;
         HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, 8 * sizeof(int64_t), h->stream));

@@ -24,10 +24,11 @@ def pkg():
 @pytest.mark.parametrize("d", [2, 3, 4, 5])
 def test_reference_ffi_on_the_product_library(pkg, d):
     """Exactly the reference's binding (cut_select_qp.py:297-303, :579-582), pointed at
-    libsdpcut_hip.so instead of neural_nets/NNs.so; values against the real NNs.so's (goldens)."""
+    libsdpcut_nns.so (the drop-in the package builds next to libsdpcut_hip.so) instead of neural_nets/NNs.so; values against
+    the real NNs.so's (goldens)."""
     from sdpcutsel_via_nn_amd import _capi
     _capi.load_library()      # (a process that also uses PyTorch-ROCm must import torch before the library binds a HIP runtime: INTEGRATION.md section 2)
-    nn_library = ctypes.cdll.LoadLibrary(_capi.LIB_PATH)
+    nn_library = ctypes.cdll.LoadLibrary(_capi.NNS_LIB_PATH)
     func_dim = getattr(nn_library, "neural_net_%dD" % d)
     func_dim.restype = ctypes.c_double
     input_arr = (ctypes.c_double * (d * (d + 3) // 2))()

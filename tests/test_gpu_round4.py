@@ -60,7 +60,7 @@ def test_nn_batch_and_compat_symbols_are_bit_identical_to_NNs_so(k):
     """VERDICT r3 item 6 / SURVEY 8 b: "the same 6 symbols with identical semantics (bit-identical results)".  NNs.so's outputs are a
     function of the host libm's exp; nn_batch_kernel evaluates exactly that operation sequence (csrc/libm_exp.h) in the reference's
     summation order, so the 4096 goldens recorded from the real NNs.so come back bit for bit -- through sdpcut_nn_batch and through
-    the reference's own binding (cut_select_qp.py:297-303, :579-582) on the product library."""
+    the reference's own binding (cut_select_qp.py:297-303, :579-582) on the product's NNs.so replacement (libsdpcut_nns.so)."""
     import ctypes
     from conftest import golden_nn
     from sdpcutsel_via_nn_amd import _capi
@@ -72,7 +72,7 @@ def test_nn_batch_and_compat_symbols_are_bit_identical_to_NNs_so(k):
     finally:
         sc.close()
     assert np.array_equal(y, g["nn_out"]), int((y != g["nn_out"]).sum())
-    nn_library = ctypes.cdll.LoadLibrary(_capi.LIB_PATH)
+    nn_library = ctypes.cdll.LoadLibrary(_capi.NNS_LIB_PATH)
     func = getattr(nn_library, "neural_net_%dD" % k)
     func.restype = ctypes.c_double
     input_arr = (ctypes.c_double * (k * (k + 3) // 2))()

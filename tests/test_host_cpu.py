@@ -29,6 +29,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert _capi.load_library().sdpcut_version() >= 100
+    # ... and NOTHING else (-fvisibility=hidden + csrc/exports.map): no C++ internals, no kernel stubs, none of NNs.so's names
+    exported = set(ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", built_lib], text=True).splitlines() if ln.strip())
+    assert exported == declared, exported ^ declared
 
 
 def test_header_constants_match_binding():

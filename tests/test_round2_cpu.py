@@ -59,13 +59,20 @@ def test_philox_index_sets_twin_equals_c_header(tmp_path):
 
 # ----------------------------------------------------------------------------- boundary
 def test_product_library_exports_the_reference_ffi():
-    """SURVEY 8 b: the six symbols of NNs.so (cut_select_qp.py:297-303) come from the PRODUCT library."""
+    """SURVEY 8 b: the six symbols of NNs.so (cut_select_qp.py:297-303) come from the PRODUCT -- since r5 from its NNs.so
+    replacement libsdpcut_nns.so (include/sdpcut_nns.h), which exports nothing else and binds to the GPU library privately."""
+    import subprocess
     from sdpcutsel_via_nn_amd import _capi, build
-    lib = ctypes.CDLL(build.build(verbose=False))
-    hdr = open(os.path.join(ROOT, "include", "sdpcut.h")).read()
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_capi.NNS_LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "sdpcut_nns.h")).read()
     for name in _capi.COMPAT_SYMBOLS:
         assert hasattr(lib, name), name
         assert name + "(" in hdr
+    exported = set(ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", _capi.NNS_LIB_PATH], text=True).splitlines() if ln.strip())
+    assert exported == set(_capi.COMPAT_SYMBOLS), exported
+    needed = subprocess.check_output(["readelf", "-d", _capi.NNS_LIB_PATH], text=True)
+    assert "amdhip" not in needed and "sdpcut_hip" not in needed      # no HIP runtime of its own, the GPU library is dlopen'ed RTLD_LOCAL
     # without a GPU the call says so and returns NaN (the signature has no error channel)
     import torch
     if not torch.cuda.is_available():

@@ -1,0 +1,83 @@
+"""Round-5 CPU tests: the bench line's parity object, the CPU baseline's core count, the exact-eigenvalue helper of the
+trajectory replay, the launcher's refusal under a profiler preload."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_selection_parity_object(oracle):
+    """bench.selection_parity (what BENCH_rNN.json's `parity` comes from): identical rounds say so; a swapped pair, a foreign id and a
+    score deviation are counted."""
+    import bench
+    rng = np.random.default_rng(4)
+    n, sel = 20000, 500
+    obj = rng.normal(size=n) * 10
+    lam = rng.normal(size=n) * 0.1
+    max_elem = np.full(n, 150.0)
+    for strat in (1, 2, 4):
+        order, scores, new_strat, _ = oracle.rank_arrays(strat, None if strat == 1 else obj, None if strat == 2 else lam, sel)
+        rec = dict(idx=order[:sel].copy(), score=scores[:sel].copy(), new_strat=new_strat,
+                   eig=None if strat == 2 else lam.copy(), obj=None if strat == 1 else obj.copy())
+        par = bench.selection_parity(oracle, strat, None if strat == 1 else obj, None if strat == 2 else lam, max_elem, sel, rec)
+        assert par["topk_identical"] and par["positions_differing"] == 0 and par["ids_one_side_only"] == 0 and par["new_strategy_identical"]
+        assert par["head"] == par["gpu_head"] == sel and par["max_abs_d_head_score"] == 0.0
+        bad = dict(rec, idx=rec["idx"].copy())
+        bad["idx"][[3, 4]] = bad["idx"][[4, 3]]                     # two neighbours swapped
+        bad["idx"][-1] = order[sel + 7]                              # an id the oracle's head does not hold
+        if strat != 2:
+            bad["eig"] = lam + 3e-15
+        par = bench.selection_parity(oracle, strat, None if strat == 1 else obj, None if strat == 2 else lam, max_elem, sel, bad)
+        assert not par["topk_identical"] and par["positions_differing"] == 3 and par["ids_one_side_only"] == 2
+        if strat != 2:
+            assert abs(par["max_abs_d_eig"] - 3e-15) < 1e-16
+
+
+def test_host_cores_is_what_the_process_may_use():
+    import bench
+    cores, how = bench.host_cores()
+    assert 1 <= cores <= len(os.sched_getaffinity(0)) and "sched_getaffinity" in how
+
+
+def test_exact_lambda_min_helper():
+    """tests/exact_eig.py: integer characteristic polynomial + 80-digit root, against LAPACK on generic and on exactly singular
+    lifted matrices (a McCormick-vertex matrix has lambda_min = 0 exactly; LAPACK returns 1e-17-level noise)."""
+    import exact_eig
+    rng = np.random.default_rng(2)
+    for k in (2, 3, 4, 5):
+        for _ in range(25):
+            x, X = rng.random(k), rng.random(k * (k + 1) // 2) * 0.5
+            A = exact_eig.lifted_full(k, x, X)
+            lap = np.linalg.eigvalsh(A)[0]
+            t = exact_eig.exact_lambda_min(A, lap)
+            assert abs(float(t) - lap) <= 4e-15
+            cf = exact_eig.charpoly_exact(A)
+            # the polynomial vanishes at the exact root to 60 digits, and LAPACK's other eigenvalues are near-roots too
+            from decimal import Decimal
+            p = Decimal(0)
+            for a in cf:
+                p = p * t + Decimal(a.numerator) / Decimal(a.denominator)
+            assert abs(p) < Decimal(10) ** -50
+    A = exact_eig.lifted_full(3, [0.5, 0.5, 0.5], [0.5, 0.0, 0.5, 0.5, 0.0, 0.5])
+    assert abs(exact_eig.exact_lambda_min(A, np.linalg.eigvalsh(A)[0])) < 1e-50
+
+
+def test_self_launch_refuses_under_a_profiler_preload():
+    """`python bench.py --gpus N` must not start ranks from a process a profiler has attached to (the preload
+    initialises the GPU in the parent; the exec that follows is what this pool's machines refuse)."""
+    env = dict(os.environ, ROCPROFILER_REGISTER_TEST="1", SDPCUT_BENCH_LAUNCH_ONLY="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 2 and b"refusing to self-launch" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode != 0 and b"WORLD_SIZE=2" in out.stderr
