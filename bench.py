@@ -569,7 +569,11 @@ def self_launch(n_ranks):
     # A profiler's preload (rocprofv3: LD_PRELOAD / ROCP* variables) initialises the GPU in THIS process before main() runs, and
     # starting the ranks from a process that holds a GPU is the exec this pool's machines refuse.  Profile one rank
     # (`rocprofv3 ... -- python3 bench.py --gpus 1`) or put the profiler inside the launch (`torch.distributed.run ... rocprofv3`).
-    preload = [k for k in os.environ if k == "LD_PRELOAD" or k.startswith("ROCP") or k.startswith("ROCPROF")]
+    # (LD_PRELOAD alone says nothing: the pool's own boxes preload a bookkeeping hook into every process.  rocprofv3 announces
+    # itself through ROCP_TOOL_LIBRARIES / ROCPROFILER_* and a preload of its tool library.)
+    preload = [k for k in os.environ if k.startswith("ROCP_TOOL") or k.startswith("ROCPROFILER_")]
+    if any(t in os.environ.get("LD_PRELOAD", "").lower() for t in ("rocprof", "roctracer")):
+        preload.append("LD_PRELOAD=" + os.environ["LD_PRELOAD"])
     if preload:
         sys.stderr.write("bench.py: refusing to self-launch %d ranks under a profiler / preload (%s): the parent must not have touched "
                          "a GPU.  Profile a single rank, or launch with torch.distributed.run and profile inside it.\n"

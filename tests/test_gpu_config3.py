@@ -62,14 +62,20 @@ def _trajectories():
 # pair, not an ordering rule.  At generic LP points the inverted pairs are additionally PINNED by id: a third pair fails.
 ADMITTED_PAIRS = {
     # (trajectory, round): inverted pairs (ids in the reference's order)
-    ("rounds_spar125_075_1_d4_s4", 5): [(806014, 803286)],       # permuted copies of ONE matrix: exact eigenvalues equal, LAPACK puts them 2.8e-16 apart
-    ("rounds_spar125_075_2_d3_s4", 2): None,                      # filled from the diagnostic run below
-    ("rounds_spar125_075_2_d3_s4", 18): None,
+    # permuted copies of ONE matrix: exact eigenvalues EQUAL, the reference's LAPACK puts them 2.8e-16 apart
+    ("rounds_spar125_075_1_d4_s4", 5): [(806014, 803286)],
+    # obj_improve + 1000 (cut_select_qp.py:611): the reference's own obj_improve of the two members differ by 3.4e-13 / by nothing,
+    # the device's MLP (MFMA summation order) is 1e-13 .. 1e-12 from NNs.so on them -- 1e-15 of the score, BASELINE grants 1e-6
+    ("rounds_spar125_075_2_d3_s4", 2): [(41980, 110560), (98522, 87399)],
+    # third LP of the pure-feasibility run: six pairs of EXACTLY equal eigenvalues (permuted copies), 1e-16 apart in LAPACK
+    ("rounds_spar080_075_1_d4_s1", 3): [(51053, 57454), (80443, 223334), (185697, 126667), (207046, 206215), (223365, 80472),
+                                        (234718, 222031)],
 }
-# the McCormick vertex and the two LPs after it under PURE feasibility (x = 0.5, X in {0, 0.5}: 2 / 245 / thousands of distinct
-# eigenvalues in a head of 5000): exact tie groups, whose members LAPACK's rounding orders -- too many pairs to name, every
-# inverted pair is still proven as above (stated deviation 1)
-STRUCTURED_ROUNDS = {("rounds_spar080_075_1_d4_s1", 1), ("rounds_spar080_075_1_d4_s1", 2), ("rounds_spar080_075_1_d4_s1", 3)}
+# the McCormick vertex and the LP after it under PURE feasibility (x = 0.5, X in {0, 0.5}: 2 and 245 distinct eigenvalues in a
+# head of 5000): exact tie groups whose members LAPACK's rounding orders and, where a group straddles position 5000, selects --
+# 2.8e6 / 1.6e6 inverted pairs, too many to name; every one of them is still proven as above: round 1 true difference 0 for all,
+# round 2 at most 2.4e-16 (measured budgets 5.6e-16 / 9.9e-16).  DESIGN.md section 2, stated deviation 1.
+STRUCTURED_ROUNDS = {("rounds_spar080_075_1_d4_s1", 1), ("rounds_spar080_075_1_d4_s1", 2)}
 EIG_ERR_MAX = 2e-15
 OBJ_ERR_REL = 1e-9
 
@@ -179,7 +185,7 @@ def test_replay_of_the_reference_trajectory(path, oracle):
         assert N == int(g["nb_subproblems"])
         rounds = int(g["rounds_done"])
         assert rounds >= 3
-        report, seen = [], set()
+        report = []
         for r in range(1, rounds + 1):
             p = "r%02d_" % r
             strat = int(g[p + "strat"])
@@ -207,7 +213,6 @@ def test_replay_of_the_reference_trajectory(path, oracle):
                     assert want is not None and pairs is not None and sorted(map(tuple, map(sorted, pairs))) == sorted(map(tuple, map(sorted, want))), (key, pairs)
                 else:
                     assert strat == 1, (r, strat)
-                seen.add(key)
             nb_cuts = int((res["lam"] < -1e-15).sum())
             assert nb_cuts == int(g[p + "nb_cuts"]), (r, nb_cuts)
             report.append("%s dim %d round %2d strategy %d -> %d: %d candidates, head %d, positions with another id %d, "

@@ -69,7 +69,7 @@ def test_exact_lambda_min_helper():
 def test_self_launch_refuses_under_a_profiler_preload():
     """`python bench.py --gpus N` must not start ranks from a process a profiler has attached to (the preload
     initialises the GPU in the parent; the exec that follows is what this pool's machines refuse)."""
-    env = dict(os.environ, ROCPROFILER_REGISTER_TEST="1", SDPCUT_BENCH_LAUNCH_ONLY="1")
+    env = dict(os.environ, ROCP_TOOL_LIBRARIES="librocprofiler-sdk-tool.so", SDPCUT_BENCH_LAUNCH_ONLY="1")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
