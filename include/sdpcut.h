@@ -96,9 +96,14 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * whose list is SHORT and whose rounds run next to another handle's (the QCQP round's objective cover beside its constraints
  * cover, sdpcut_round_csr_begin): its few small kernels are then dispatched ahead of the other list's waiting workgroups instead of
  * behind them.  Not allowed while a round is pending; ignored by a handle that runs on a caller's stream (sdpcut_set_stream). */
+/* SDPCUT_OPT_PREFILTER (default 1; needs SDPCUT_OPT_FUSE_KEYS): the score / eigenvalue kernels of a fused round also count the class
+ * members by the top sixteen bits of their selection keys (a 1024-bin window; one LDS atomic per candidate, reported when a
+ * workgroup retires, only from the current lower bound of the k-th largest key upwards).  The selection then resolves two digits
+ * without reading a key and compacts the head's superset in one pass without grid barriers.  0: the radix passes of rounds 2-4
+ * (A/B; identical results). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
        SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6, SDPCUT_OPT_EIG_KERNEL = 7, SDPCUT_OPT_STREAM_PRIORITY = 8,
-       SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10 };
+       SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10, SDPCUT_OPT_PREFILTER = 11 };
 
 /* Counters of a handle: SDPCUT_STAT_ROUNDS = fused rounds served (sdpcut_select_round*),
  * SDPCUT_STAT_SELECT_FALLBACKS = rounds whose radix selection declared itself void (a grid barrier
@@ -107,8 +112,12 @@ enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, S
  * SDPCUT_STAT_SCORED = the measures (SDPCUT_EIG | SDPCUT_NN) scored at the current point.
  * SDPCUT_STAT_TIE_SPLITS (r4) = every-entry-visited combined rankings whose threshold group of EQUAL new scores
  * did not fit the sort buffers (structured LP vertices) and was cut by its secondary key -- obj_improve, then index,
- * cut_select_qp.py:601 under :625 -- with two more radix selections; until round 3 these rounds were fallbacks. */
-enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3, SDPCUT_STAT_TIE_SPLITS = 4 };
+ * cut_select_qp.py:601 under :625 -- with two more radix selections; until round 3 these rounds were fallbacks.
+ * SDPCUT_STAT_DIRECT_SELECTIONS (r5) = selections resolved from the fine histogram the score kernels leave (no digit pass, no grid
+ *   barrier: SDPCUT_OPT_PREFILTER); the others ran the radix passes (short lists, masses of equal keys at the threshold, the
+ *   every-entry-visited regime).  Read from the device: the call waits for the handle's stream.  Same results either way. */
+enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3, SDPCUT_STAT_TIE_SPLITS = 4,
+       SDPCUT_STAT_DIRECT_SELECTIONS = 5 };
 int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value);
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */

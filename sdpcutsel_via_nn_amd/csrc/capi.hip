@@ -125,7 +125,9 @@ int sdpcut_create(int device_id, sdpcut_handle *out)
     h->device = device_id;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&h->d_counters, 8 * sizeof(int64_t)) != hipSuccess) {
+        hipMalloc((void **)&h->d_counters, 8 * sizeof(int64_t)) != hipSuccess ||
+        hipMalloc((void **)&h->d_stats, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(h->d_stats, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
         delete h;
         return sdpcut_fail(nullptr, SDPCUT_EHIP, "stream / counter allocation failed");
     }
@@ -180,6 +182,7 @@ int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap,
             ScoreFuse fuse;
             fuse.ws = ws;
             fuse.mode = fast_mode;
+            fuse.k = h->prefilter ? cap : 0;
             rc = launch_score(h, need, &fuse, &counted, strong);
         } else {
             rc = launch_score(h, need, nullptr, nullptr, strong);
@@ -210,7 +213,7 @@ int sdpcut_destroy(sdpcut_handle h)
     if (h->point_stage) (void)hipHostFree(h->point_stage);
     (void)hipFree(h->d_done_ticket);
     for (int k = 0; k <= SDPCUT_MAX_K; ++k) hipFree(h->net[k].d_blob);
-    hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage);
+    hipFree(h->d_Q); hipFree(h->d_vars); hipFree(h->d_counters); hipFree(h->d_stage); hipFree(h->d_stats);
     for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 3; ++i) {
         if (h->side_stream[i]) hipStreamDestroy(h->side_stream[i]);
@@ -252,6 +255,9 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value)
     case SDPCUT_OPT_ONE_LAUNCH:
         h->one_launch = value != 0;
         return SDPCUT_OK;
+    case SDPCUT_OPT_PREFILTER:
+        h->prefilter = value != 0;
+        return SDPCUT_OK;
     case SDPCUT_OPT_SIDE_STREAMS:
         if (value < 0 || value > 2) return sdpcut_fail(h, SDPCUT_EINVAL, "SDPCUT_OPT_SIDE_STREAMS: 0 off, 1 on, 2 measured");
         h->side_streams = (int)value;
@@ -287,6 +293,14 @@ int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value)
     case SDPCUT_STAT_SELECT_FALLBACKS: *value = h->stat_fallbacks; return SDPCUT_OK;
     case SDPCUT_STAT_SCORED: *value = h->have_point ? (int64_t)h->scored : 0; return SDPCUT_OK;
     case SDPCUT_STAT_TIE_SPLITS: *value = h->stat_tie_splits; return SDPCUT_OK;
+    case SDPCUT_STAT_DIRECT_SELECTIONS: {
+        unsigned long long v = 0;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(&v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, sdpcut_sync(h));
+        *value = (int64_t)v;
+        return SDPCUT_OK;
+    }
     }
     return sdpcut_fail(h, SDPCUT_EINVAL, "unknown statistic");
 }

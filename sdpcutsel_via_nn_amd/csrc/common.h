@@ -87,6 +87,8 @@ struct sdpcut_ctx {
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     bool eig_kernel = true;        // SDPCUT_OPT_EIG_KERNEL: eigenvalue-only launches run eig_only_kernel (eig.hip)
+    bool prefilter = true;         // SDPCUT_OPT_PREFILTER: fine histogram in the score kernels, direct selection (topk_dev.h)
+    unsigned long long *d_stats = nullptr;   // device counters that outlive a round: [0] direct selections
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)
     int64_t stat_rounds = 0, stat_fallbacks = 0, stat_tie_splits = 0;   // sdpcut_get_stat
     int timing = 0;                // 0 off, 1 events around the score kernel, 2 also around the ranking
@@ -186,6 +188,7 @@ void free_candidates(sdpcut_ctx *h);             // capi.hip: drop the handle's 
 struct ScoreFuse {
     void *ws;
     int mode;      // TK_MODE_FEAS / OPT / STRONG of topk_dev.h: whose keys to count
+    int64_t k;     // head size of the selection (the streaming prefilter's bound rises to the k-th largest key); 0: no fine histogram
 };
 // strong_out (optional, device, 8 int64 replicas): the launches add the number of candidates with
 // obj_improve > 0 and lambda_min < -1e-15 to strong_out[workgroup % 8] (needs both flags; used by the device-resolved combined selection)
@@ -204,7 +207,7 @@ CsrLayout csr_layout(int64_t cap, int ld);
 int launch_round_csr(sdpcut_ctx *h, int64_t cap, const int64_t *d_c4, int64_t limit, const int64_t *d_idx, const double *d_score,
                      int ld, void *block, int64_t serial);
 // eig.hip: lambda_min of every candidate, one launch over all size classes; tk = TopkWs of a feasibility selection or NULL
-int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_stop);
+int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_stop, int64_t pf_k = 0);
 int wait_round_done(sdpcut_ctx *h, const int64_t *word, int64_t serial);   // capi.hip
 int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap, uint32_t need, bool allow_auto, int *stage,
                         bool *auto_out);                                   // capi.hip

@@ -33,6 +33,7 @@ struct EigArgs {
     int64_t L;
     double *eig_out;
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
+    int64_t pf_k;    // FUSE: head size of that selection (streaming prefilter, topk_dev.h); 0: no fine histogram
 };
 
 // ---- re-packing the lanes that have not converged ------------------------------------------------------------
@@ -74,7 +75,9 @@ __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t o
     if (live) A.eig_out[out_idx] = lam;
     if constexpr (FUSE) {
         const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
-        hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
+        const uint64_t key = key_of(-lam);
+        hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
+        if (viol) atomicAdd(&tk_hist[256 + pf_wcode(key, pf_base(true))], 1u);      // (the prefilter's table sits behind the histogram)
         c_viol += viol;
     }
 }
@@ -193,14 +196,15 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256];
+    __shared__ uint32_t tk_hist[256 + (FUSE ? PF_BINS : 0)];      // leading-digit histogram | (r5) streaming prefilter table
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];
     __shared__ uint32_t s_packed[2];      // packed-lane counters of the current / the next tile
     if (threadIdx.x < 2) s_packed[threadIdx.x] = 0;
     if constexpr (FUSE) {
-        tk_hist[threadIdx.x] = 0;
+#pragma unroll
+        for (int j = 0; j < 1 + PF_BINS / 256; ++j) tk_hist[threadIdx.x + 256 * j] = 0;
         if (threadIdx.x == 0) tk_cnt = 0;
     }
     __syncthreads();
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+        if (A.pf_k > 0) pf_retire(A.tk, tk_hist + 256, A.pf_k);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -247,7 +252,7 @@ static void eig_launch(sdpcut_ctx *h, const EigArgs &A, hipEvent_t ev_start, hip
 
 // lambda_min of every candidate of the handle's list at the current point, one launch.
 // tk != nullptr: also the leading-digit histogram / violated count of a feasibility selection (TopkWs).
-int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_stop)
+int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_stop, int64_t pf_k)
 {
     EigArgs A;
     int kmax = 0;
@@ -261,7 +266,7 @@ int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_
     }
     A.set[0] = A.set[1] = nullptr; A.orig[0] = A.orig[1] = nullptr; A.n[0] = A.n[1] = 0; A.tile_end[0] = A.tile_end[1] = acc;
     if (kmax == 0) return 0;
-    A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk;
+    A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk; A.pf_k = tk ? pf_k : 0;
 #define EIG_LAUNCH(KM)                                                   \
     do {                                                                 \
         if (tk) eig_launch<KM, true>(h, A, ev_start, ev_stop);           \

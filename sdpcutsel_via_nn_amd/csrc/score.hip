@@ -57,6 +57,7 @@ struct ScoreArgs {
     // the selection never looks below the class.
     TopkWs *tk;
     int tk_mode;           // TK_MODE_FEAS / OPT / STRONG: the kernel's FUSE template argument
+    int64_t pf_k;          // head size of that selection: the streaming prefilter's bound (topk_dev.h) rises to the pf_k-th largest key; 0: no fine histogram
     // optional: += number of candidates with obj_improve > 0 and lambda_min < -1e-15 (the "strong" class
     // of the combined strategy, cut_select_qp.py:607-613); lets the selection that follows pick its
     // regime on the device.  Needs both flags.
@@ -472,6 +473,7 @@ struct MfmaLds {
     uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
     uint32_t tk_cnt[2];
     uint32_t s_strong;
+    uint32_t pf_tab[PF_BINS];    // (r5) the class members by window code: the streaming prefilter's table (topk_dev.h)
 };
 
 // bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
@@ -558,9 +560,13 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     auto &tk_hist = S.tk_hist;
     auto &tk_cnt = S.tk_cnt;
     uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
+    auto &pf_tab = S.pf_tab;
+    const int pf_b = pf_base(FUSE == TK_MODE_FEAS);
     if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
+#pragma unroll
+        for (int j = 0; j < PF_BINS / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
         __syncthreads();
     }
 
@@ -600,7 +606,9 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         if (!(A.flags & SDPCUT_NN)) {           // uniform branch
             if constexpr (FUSE != 0) {
                 const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
-                hist_add_few(tk_hist, (uint32_t)(key_of(-lam) >> 56), viol);
+                const uint64_t key = key_of(-lam);
+                hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
+                if (viol) atomicAdd(&pf_tab[pf_wcode(key, pf_b)], 1u);
                 c_viol += viol;
             }
             tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
@@ -827,7 +835,9 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 c_viol += viol;
                 c_pos += pos;
                 const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
-                hist_add_few(tk_hist, (uint32_t)(key_of(FUSE == TK_MODE_FEAS ? -lam : obj) >> 56), member);
+                const uint64_t key = key_of(FUSE == TK_MODE_FEAS ? -lam : obj);
+                hist_add_few(tk_hist, (uint32_t)(key >> 56), member);
+                if (member) atomicAdd(&pf_tab[pf_wcode(key, pf_b)], 1u);      // (LDS, no return value: one ds_add per candidate)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
@@ -866,6 +876,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+        if (A.pf_k > 0) pf_retire(A.tk, pf_tab, A.pf_k);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -1273,6 +1284,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
     A.tk_mode = fuse ? fuse->mode : 0;
+    A.pf_k = fuse ? fuse->k : 0;
     A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
     A.net = h->net[K].dev;
     if ((flags & SDPCUT_NN) && !h->net[K].set)
@@ -1359,6 +1371,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
         A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
         A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
         A.tk_mode = f;
+        A.pf_k = fuse ? fuse->k : 0;
         A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
         A.net = h->net[k].dev;
         int grid = grid_for(h, (b.n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
@@ -1495,7 +1508,8 @@ int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fus
         if (fuse && fuse->mode != TK_MODE_FEAS)
             return sdpcut_fail(h, SDPCUT_EINVAL, "score: the selection mode ranks by a measure this launch does not compute");
         h->timed_score = h->timing != 0 && h->N > 0;
-        return launch_eig_only(h, fuse ? fuse->ws : nullptr, h->timed_score ? h->ev[0] : nullptr, h->timed_score ? h->ev[1] : nullptr);
+        return launch_eig_only(h, fuse ? fuse->ws : nullptr, h->timed_score ? h->ev[0] : nullptr, h->timed_score ? h->ev[1] : nullptr,
+                               fuse ? fuse->k : 0);
     }
     int nclasses = 0, kbig = 0;
     for (int k = 2; k <= SDPCUT_MAX_K; ++k)

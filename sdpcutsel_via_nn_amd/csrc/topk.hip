@@ -159,10 +159,16 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 // Mode COMBAUTO resolved to COMBALL (fewer strong candidates than asked for -- the score kernels
 // counted the STRONG keys): this launch runs its own pass 0 first, histogram in TopkWs::hist_alt.
 #define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
+// (r5) DIRECT: the score / eigenvalue kernels also left the FINE histogram of the class (TopkWs::pf_tab, "streaming prefilter" in
+// topk_dev.h).  Every workgroup resolves from it the window bin e* that holds the k-th largest key; if the members at or above e*
+// fit the sort buffers -- the usual case: 5000 .. 6500 of 10^6 -- they are compacted in ONE pass over the scores and handed to the
+// sort exactly like an early stop of the digit passes: no histogram pass, no grid barrier, no wait (25.8 -> ~12 us on the 10^6-
+// candidate round).  pf_k = 0, a fat bin, or the every-entry-visited regime: the passes below run as before.
 template <bool ONFLY>
 __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
                                                                TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx, int mode,
-                                                               int64_t sel, const double *eig, const double *obj)
+                                                               int64_t sel, const double *eig, const double *obj, int64_t pf_k,
+                                                               unsigned long long *d_stats)
 {
     __shared__ uint32_t hist[256];
     __shared__ int go;
@@ -177,6 +183,9 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     bool cached = false;
     int last_pass = -1;                             // last digit pass this launch ran (its histogram is still in LDS)
     int p_first = 1;
+    bool direct = false;                            // (r5) resolved from the fine table: uniform over the grid
+    __shared__ int pf_e;
+    __shared__ int64_t pf_count;
     if (threadIdx.x == 0) c_above = 0;
     auto key_at = [&](int64_t i) -> uint64_t {
         if constexpr (ONFLY) return masked_key(mode, eig[i], obj[i]);     // (both valid: see the launch)
@@ -217,12 +226,97 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             p_first = 0;
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
-            resolve_digit(ws, 0, k, ws->hist_score, cls, &st1, blockIdx.x == 0, mode, true, TK_SHREP);
+            if (pf_k > 0 && mode != TK_MODE_COMBALL) {
+                // ---- the fine table: bins 4 t .. 4 t + 3 of this thread, suffix sums from the top (plain loads: an earlier launch wrote them)
+                __shared__ uint32_t pf_wtot[TK_THREADS / 64];
+                const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
+                uint32_t h4[PF_BINS / TK_THREADS], mine4 = 0;
+#pragma unroll
+                for (int j = 0; j < PF_BINS / TK_THREADS; ++j) { h4[j] = ws->pf_tab[(PF_BINS / TK_THREADS) * t + j]; mine4 += h4[j]; }
+                uint32_t v = mine4;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_down((int)v, off);
+                    if (ln + off < 64) v += o;
+                }
+                if (ln == 0) pf_wtot[wv] = v;
+                if (t == 0) { pf_e = -1; pf_count = 0; }
+                __syncthreads();
+                for (int w = wv + 1; w < TK_THREADS / 64; ++w) v += pf_wtot[w];
+                const int64_t need = k < cls ? k : cls;
+                int64_t above = (int64_t)(v - mine4);
+#pragma unroll
+                for (int j = PF_BINS / TK_THREADS - 1; j >= 0; --j) {
+                    const int64_t here = above + (int64_t)h4[j];
+                    if (need >= 1 && here >= need && above < need) { pf_e = (PF_BINS / TK_THREADS) * t + j; pf_count = here; }      // one bin of one thread
+                    above = here;
+                }
+                __syncthreads();
+                const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
+                // (e* below the bound cannot happen -- at least k members were counted at or above the bound -- but an incomplete bin
+                // must never be trusted: checked)
+                direct = pf_e >= 0 && pf_count <= maxk && (uint32_t)pf_e >= ws->pf_bound;
+                if (direct) {
+                    const bool all_members = mode == TK_MODE_OPT;
+                    const uint64_t edge = pf_edge(pf_e, pf_base(mode == TK_MODE_FEAS));
+                    if (threadIdx.x == 0) {
+                        st1.prefix = edge > 0ull || all_members ? edge : 1ull;      // (key 0 = not in the class)
+                        st1.need = 1;
+                        st1.stop = 1;
+                        if (blockIdx.x == 0) {
+                            st_i64(&ws->counters[3], need);      // k_eff for the sort
+                            if (d_stats) atomicAdd(&d_stats[0], 1ull);
+                        }
+                    }
+                }
+            }
+            if (!direct) resolve_digit(ws, 0, k, ws->hist_score, cls, &st1, blockIdx.x == 0, mode, true, TK_SHREP);
         }
         __syncthreads();
     }
     TkState st;
-    for (int p = p_first;; ++p) {
+    if (direct) {
+        // ---- one pass: the keys of this chunk (into the LDS cache when they fit), how many of them lie at or above the edge
+        st = st1;
+        const uint64_t T0 = st.prefix;
+        uint32_t my = 0;
+        if (threadIdx.x == 0) c_gt = 0;
+        __syncthreads();
+        if constexpr (ONFLY) {
+            for (int64_t r0 = lo; r0 < hi; r0 += (int64_t)TK_UNROLL * TK_THREADS) {
+                double e[TK_UNROLL], o[TK_UNROLL];
+                bool in[TK_UNROLL];
+                if (r0 == lo) {      // uniform: the batch requested at the top of the kernel
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        in[u] = lo + (int64_t)u * TK_THREADS + threadIdx.x < hi;
+                        e[u] = pre_e[u];
+                        o[u] = pre_o[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                        in[u] = i < hi;
+                        const int64_t ic = in[u] ? i : hi - 1;
+                        e[u] = eig[ic];
+                        o[u] = obj[ic];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = r0 + (int64_t)u * TK_THREADS + threadIdx.x;
+                    const uint64_t key = in[u] ? masked_key(mode, e[u], o[u]) : 0ull;
+                    if (use_cache && in[u]) cache[i - lo] = key;
+                    my += in[u] && key >= T0;
+                }
+            }
+        }
+        cached = use_cache;
+        for (int off = 32; off > 0; off >>= 1) my += __shfl_xor((int)my, off);
+        if ((threadIdx.x & 63) == 0 && my) atomicAdd(&c_gt, my);
+        __syncthreads();
+    }
+    for (int p = p_first; !direct; ++p) {
         if (p > p_first) {        // state[p] is published inside this launch
             if (threadIdx.x == 0) {
                 int ok = 1;
@@ -325,6 +419,8 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if (lane == 0 && part) atomicAdd(&c_gt, part);
             __syncthreads();
             mine = c_gt + c_above;
+        } else if (direct) {
+            mine = c_gt;                                   // counted by the direct pass above
         } else {
             if (threadIdx.x == 0) c_gt = 0;
             __syncthreads();
@@ -1446,15 +1542,18 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             uint32_t *si_arg = h->d_sel_idx;
             int64_t n_arg = n, k_arg = k, chunk_arg = chunk, sel_arg = sel;
             int mode_arg = mode;
-            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg, &mode_arg, &sel_arg, &eig, &obj};
+            int64_t pf_arg = 0;
+            unsigned long long *stats_arg = nullptr;
+            void *args[] = {&n_arg, &k_arg, &chunk_arg, &keys_arg, &ws, &sk_arg, &si_arg, &mode_arg, &sel_arg, &eig, &obj, &pf_arg, &stats_arg};
             if (onfly)      // (a measure the mode does not use is never looked at: any readable array of n doubles will do)
                 hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, nullptr, ws,
-                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig);
+                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig,
+                                   (int64_t)(h->prefilter ? k : 0), h->d_stats);
             else if (h->coop_launch)      // the runtime guarantees the co-residency (+20 us per launch)
                 HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else
                 hipLaunchKernelGGL(tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, h->d_key_a, ws,
-                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig, obj);
+                                   h->d_sel_key, h->d_sel_idx, mode, sel, eig, obj, (int64_t)0, (unsigned long long *)nullptr);
         } else {
             // one launch per digit, no wait anywhere inside a kernel: the path that always answers (each launch returns at
             // once when the selection has been closed by an earlier digit)

@@ -33,6 +33,35 @@
 // deep on every cell (+11 us on a 48 us kernel), with 32 the chains are ~120 deep and hidden behind the kernel's tail.
 #define TK_SHREP 32
 
+// ---- streaming prefilter (r5) ---------------------------------------------------------------------------------------
+// The LEADING byte of a key image (sign + seven exponent bits) is shared by nearly every member of a class, so the
+// leading-digit histogram the score kernels count (hist_score) only saves the selection its first pass: tk_refine_kernel still
+// ran one or two histogram passes behind grid barriers over all 10^6 keys to find ~5000 of them (25 us of a 387 us round,
+// 75 % of what a feasibility round spends outside its 28 us eigenvalue kernel).  Now the kernels that produce the scores also
+// count the members by the top SIXTEEN bits of the key (sign, exponent, four mantissa bits: 6 % resolution) inside a window of
+// 1024 codes -- one LDS atomic per candidate into a per-workgroup table -- and report the table when they retire.  A retiring
+// workgroup first reads the bound pf_bound and reports only the bins at or above it; every eighth one then scans the global
+// table and raises the bound to the highest bin with at least k members at or above it (counts only grow: the bound is a valid
+// lower bound of the k-th largest key from then on).  Once the first generation of workgroups has reported, a workgroup
+// reports the handful of bins its top 1-2 % of candidates fall into: ~1e5 no-return atomics per 10^6 candidates, none of them
+// on anybody's critical path.  At the end every bin at or above the final bound is EXACT (every workgroup reported all of its
+// members there), and the bin e* of the k-th largest key lies at or above the bound: the selection resolves two digits without
+// reading a key and -- when the members at or above e* fit the sort buffers, the usual case -- compacts them in ONE pass
+// without a grid barrier (tk_refine_kernel, `direct`).  Otherwise (a fat bin: masses of equal keys at a structured LP
+// vertex; the every-entry-visited regime, whose keys are not the ones counted) the passes run as before.
+// Window: codes [base, base + 1023], clamped on both sides (the lowest bin also holds everything below, the highest
+// everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
+#define PF_BINS 1024
+#define PF_UPDATE_EVERY 8      // every n-th retiring workgroup raises the bound
+__device__ __forceinline__ int pf_base(bool feas) { return (feas ? 0xC070 : 0xC170) - (PF_BINS - 1); }
+__device__ __forceinline__ int pf_wcode(uint64_t key, int base)
+{
+    const int c = (int)(uint32_t)(key >> 48) - base;
+    return c < 0 ? 0 : (c > PF_BINS - 1 ? PF_BINS - 1 : c);
+}
+// lowest key of window bin e (0: everything)
+__device__ __forceinline__ uint64_t pf_edge(int e, int base) { return e <= 0 ? 0ull : (uint64_t)(uint32_t)(base + e) << 48; }
+
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
 // 5: combined strategy, regime resolved ON THE DEVICE by the first pass: STRONG if the score kernels
@@ -71,6 +100,10 @@ struct TopkWs {
     int64_t viol_rep[TK_SHREP];           // violated / positive candidates counted by the same kernels, replicated by workgroup:
     int64_t pos_rep[TK_SHREP];            // ONE counter each would queue thousands of retiring workgroups on one address (~15 ns
                                           // apiece: 58 us for the eigenvalue kernel's 3907 workgroups -- longer than the kernel runs)
+    // (r5) the FINE histogram the score / eigenvalue kernels leave for the selection (see "streaming prefilter" below):
+    uint32_t pf_tab[PF_BINS];             // class members by window code (the top 16 bits of the key, clamped into a 1024-bin window)
+    uint32_t pf_bound;                    // bins below this one are no longer reported: at least k members lie at or above it
+    uint32_t pf_pad_;
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -117,6 +150,41 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
         rem &= ~same;
     }
     if ((rem >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+}
+
+// ---- streaming prefilter: device side of the producers (score.hip, eig.hip) ------------------------------------------
+// Report this workgroup's table (LDS, PF_BINS cells, complete: call behind a workgroup barrier) and, for every
+// PF_UPDATE_EVERY-th workgroup, raise the bound.  256 threads.
+static __device__ void pf_retire(TopkWs *ws, const uint32_t *tab, int64_t k)
+{
+    const uint32_t bound = ld_u32(&ws->pf_bound);
+#pragma unroll
+    for (int j = 0; j < PF_BINS / 256; ++j) {
+        const int bin = (int)threadIdx.x + 256 * j;
+        const uint32_t v = tab[bin];
+        if (v && (uint32_t)bin >= bound) __hip_atomic_fetch_add(&ws->pf_tab[bin], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((blockIdx.x % PF_UPDATE_EVERY) != 0 || threadIdx.x >= 64) return;      // one wave of every n-th workgroup
+    // lane l owns bins 16 l .. 16 l + 15; suffix sums from the top
+    const int lane = (int)threadIdx.x;
+    uint32_t h[PF_BINS / 64];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PF_BINS / 64; ++j) { h[j] = ld_u32(&ws->pf_tab[(PF_BINS / 64) * lane + j]); mine += h[j]; }
+    uint32_t v = mine;      // inclusive suffix sum over the lanes
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_down((int)v, off);
+        if (lane + off < 64) v += o;
+    }
+    int64_t above = (int64_t)(v - mine);
+    int found = -1;
+#pragma unroll
+    for (int j = PF_BINS / 64 - 1; j >= 0; --j) {
+        const int64_t here = above + (int64_t)h[j];
+        if (here >= k && above < k) found = (PF_BINS / 64) * lane + j;      // exactly one bin of one lane (if the table holds k members at all)
+        above = here;
+    }
+    if (found > 0) __hip_atomic_fetch_max(&ws->pf_bound, (uint32_t)found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].

@@ -92,3 +92,108 @@ def test_config4_shard_selection_equals_oracle_scored_ranking(oracle):
         check_rounds(oracle, sc, wl, 3, 5000, base=base)
     finally:
         sc.close()
+
+
+# --------------------------------------------------------------------------- streaming prefilter / direct selection
+def _round_ab(sc, strat, sel, vv):
+    """the same fused round with the fine histogram on and off -> (result on, result off, direct selections taken)"""
+    from sdpcutsel_via_nn_amd import _capi
+    out = []
+    taken = 0
+    for on in (1, 0):
+        sc.set_option(_capi.OPT_PREFILTER, on)
+        before = sc.get_stat(_capi.STAT_DIRECT_SELECTIONS)
+        out.append(sc.select_round(strat, sel, copy=True, point=vv))
+        after = sc.get_stat(_capi.STAT_DIRECT_SELECTIONS)
+        if on:
+            taken = after - before
+        else:
+            assert after == before
+    sc.set_option(_capi.OPT_PREFILTER, 1)
+    return out[0], out[1], taken
+
+
+def _same_round(a, b):
+    for key in ("idx", "score", "lam", "coef", "rhs", "ks"):
+        assert np.array_equal(a[key], b[key]), key
+    assert a["n_total"] == b["n_total"] and a["new_strat"] == b["new_strat"] and a["counters"] == b["counters"]
+
+
+@pytest.mark.parametrize("count,sel", [(10 ** 6, 5000), (300000, 5000), (60000, 5000), (10 ** 6, 100), (10 ** 6, 8192), (2 * 10 ** 6, 16000)])
+def test_direct_selection_equals_the_radix_passes(count, sel):
+    """The selection resolved from the fine histogram (no digit pass, no grid barrier) returns bit for bit what the radix passes
+    return -- ids, scores, eigenvalues, rows, counters -- for the three strategies, and it IS taken on generic points."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    wl = synthetic.make_workload(nb_vars=100, k=3, count=count, seed=21)
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(100, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        for strat in (4, 1, 2):
+            if strat == 4 and sel > 8192:
+                continue                      # (the combined strategy's device-resolved regime takes heads <= 8192)
+            a, b, taken = _round_ab(sc, strat, sel, wl["vars_values"])
+            _same_round(a, b)
+            assert a["idx"].shape[0] == sel
+            if count >= 10 ** 6:      # (a head that is a large share of a short list can have its threshold in a fat bin: the passes run)
+                assert taken == 1, (strat, taken)
+        assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
+    finally:
+        sc.close()
+
+
+def test_direct_selection_steps_aside_for_masses_of_equal_keys(golden_boxqp):
+    """A structured LP vertex (x = 0.5, X in {0, 0.5}: a handful of distinct eigenvalues over 1e6 candidates): the bin of the
+    threshold holds far more members than the sort buffers -- the fine histogram says so and the radix passes run (ties cut by
+    index as ever).  Same results with the option off."""
+    import sdpcutsel_via_nn_amd as pkg
+    from sdpcutsel_via_nn_amd import _capi, networks, synthetic
+    wl = synthetic.make_workload(nb_vars=60, k=3, count=400000, seed=5)
+    n = 60
+    L = n * (n + 1) // 2
+    vv = np.zeros(L + n)
+    vv[L:] = 0.5
+    rng = np.random.default_rng(1)
+    X = np.where(rng.random(L) < 0.5, 0.5, 0.0)
+    iu = np.triu_indices(n)
+    X[iu[0] == iu[1]] = 0.5
+    vv[:L] = X
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_network(3, *networks.load_network(3))
+        sc.set_instance(n, wl["Q_arr"])
+        sc.set_candidates(wl["set_inds"], wl["ks"])
+        for strat in (1, 4, 2):
+            a, b, taken = _round_ab(sc, strat, 5000, vv)
+            _same_round(a, b)
+            if strat == 1:
+                assert taken == 0 and np.unique(a["score"]).size < 50      # masses of equal eigenvalues: the passes ran
+    finally:
+        sc.close()
+
+
+def test_direct_selection_on_a_real_mixed_cover(oracle):
+    """spar125-075-1 dim 4 (1 700 215 candidates of 2..4 variables, ONE launch over the three size classes) at recorded LP
+    points: combined round 4 (generic point) and feasibility round 8 -- both resolved directly, both identical to the passes."""
+    import os
+    import sdpcutsel_via_nn_amd as pkg
+    from conftest import GOLDEN
+    from sdpcutsel_via_nn_amd import harness
+    inst = harness.parse_boxqp(os.path.join(GOLDEN, "instances", "spar125-075-1.in"))
+    g = np.load(os.path.join(GOLDEN, "rounds_spar125_075_1_d4_s4.npz"))
+    sc = pkg.Scorer(0)
+    try:
+        sc.set_builtin_networks(4)
+        sc.set_instance(inst["nb_vars"], inst["Q_arr"])
+        assert sc.set_candidates_cover(inst["adj"], 4) == 1700215
+        for r in (4, 8, 2):
+            strat = int(g["r%02d_strat" % r])
+            a, b, taken = _round_ab(sc, strat, 5000, np.ascontiguousarray(g["r%02d_vars" % r]))
+            _same_round(a, b)
+            assert np.array_equal(a["idx"], g["r%02d_ids" % r].astype(np.int64)) or r == 2
+            if r in (4, 8):
+                assert taken == 1, (r, strat, taken)
+    finally:
+        sc.close()
