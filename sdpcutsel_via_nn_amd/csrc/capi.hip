@@ -149,6 +149,7 @@ void free_candidates(sdpcut_ctx *h)
     hipFree(h->d_set_orig); hipFree(h->d_k); hipFree(h->d_eig); hipFree(h->d_obj);
     h->d_set_orig = nullptr; h->d_k = nullptr; h->d_eig = nullptr; h->d_obj = nullptr;
     h->N = 0; h->scored = 0; h->last_total = -1;
+    h->topk_alt_clean = false;      // (how much of the selection workspace a round's epilogue zeroes depends on the list's length)
     h->side_choice = -1;      // (a new list measures for itself whether its small size classes go to side streams)
 }
 
@@ -182,7 +183,7 @@ int score_for_selection(sdpcut_ctx *h, int strat, int64_t sel_size, int64_t cap,
             ScoreFuse fuse;
             fuse.ws = ws;
             fuse.mode = fast_mode;
-            fuse.k = h->prefilter ? cap : 0;
+            fuse.k = (h->prefilter && h->N >= SDPCUT_PF_MIN_N) ? cap : 0;
             rc = launch_score(h, need, &fuse, &counted, strong);
         } else {
             rc = launch_score(h, need, nullptr, nullptr, strong);

@@ -10,6 +10,10 @@
 #define SDPCUT_NEG_EIGVAL (-1e-15) /* _THRES_NEG_EIGVAL, cut_select_qp.py:24 */
 #define SDPCUT_BIG_M 1000.0        /* _BIG_M, cut_select_qp.py:26 */
 
+// lists shorter than this do not count the fine histogram of their selection (topk_dev.h): their heads come from the one-workgroup
+// selections or from passes over a few thousand keys, and their epilogues are too small to zero 34 KB more
+#define SDPCUT_PF_MIN_N 32768
+
 #define MAX_HIDDEN 64
 #define MAX_LAYERS 5
 

@@ -33,7 +33,7 @@ struct EigArgs {
     int64_t L;
     double *eig_out;
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
-    int64_t pf_k;    // FUSE: head size of that selection (streaming prefilter, topk_dev.h); 0: no fine histogram
+    int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): a tile reports its members down to its pf_mloc-th largest; 0: off
 };
 
 // ---- re-packing the lanes that have not converged ------------------------------------------------------------
@@ -70,14 +70,19 @@ constexpr int eig_pack_doubles(int kmax)
 #endif
 
 template <int K, bool FUSE>
-__device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol)
+__device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol,
+                                         int *pf_code = nullptr)
 {
     if (live) A.eig_out[out_idx] = lam;
     if constexpr (FUSE) {
         const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
         const uint64_t key = key_of(-lam);
         hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-        if (viol) atomicAdd(&tk_hist[256 + pf_wcode(key, pf_base(true))], 1u);      // (the prefilter's table sits behind the histogram)
+        if (pf_code) {      // (r5) the tile's coarse table sits behind the histogram; the fine code stays in a register until the tile retires
+            const int f = pf_fcode(key, pf_base(true));
+            *pf_code = viol ? f : -1;
+            if (viol && A.pf_mloc > 0) atomicAdd(&tk_hist[256 + (f >> 3)], 1u);
+        }
         c_viol += viol;
     }
 }
@@ -95,7 +100,14 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
 #if SDPCUT_LMIN
     // (r4) Householder + Laguerre, Jacobi for the lanes it hands back: no re-packing (the lanes Jacobi is left with are a few
     // per cent at structured vertices, none at generic points)
-    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol);
+    int pf_code = -1;
+    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_code);
+    if constexpr (FUSE) {
+        if (A.pf_mloc > 0) {      // uniform: the tile reports the top of its table (two barriers; every thread of the workgroup is here)
+            __syncthreads();
+            pf_retire_keys(A.tk, tk_hist + 256, A.pf_mloc, pf_code >= 0, pf_code);
+        }
+    }
     (void)s_state; (void)s_out; (void)cnt;
     return;
 #endif
@@ -196,7 +208,7 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256 + (FUSE ? PF_BINS : 0)];      // leading-digit histogram | (r5) streaming prefilter table
+    __shared__ uint32_t tk_hist[256 + (FUSE ? PF_CBINS : 0)];      // leading-digit histogram | (r5) coarse table of the current tile (topk_dev.h)
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
     if (threadIdx.x < 2) s_packed[threadIdx.x] = 0;
     if constexpr (FUSE) {
 #pragma unroll
-        for (int j = 0; j < 1 + PF_BINS / 256; ++j) tk_hist[threadIdx.x + 256 * j] = 0;
+        for (int j = 0; j < 1 + PF_CBINS / 256; ++j) tk_hist[threadIdx.x + 256 * j] = 0;
         if (threadIdx.x == 0) tk_cnt = 0;
     }
     __syncthreads();
@@ -228,7 +240,6 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-        if (A.pf_k > 0) pf_retire(A.tk, tk_hist + 256, A.pf_k);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -266,7 +277,15 @@ int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_
     }
     A.set[0] = A.set[1] = nullptr; A.orig[0] = A.orig[1] = nullptr; A.n[0] = A.n[1] = 0; A.tile_end[0] = A.tile_end[1] = acc;
     if (kmax == 0) return 0;
-    A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk; A.pf_k = tk ? pf_k : 0;
+    A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk;
+    // a tile of 256 candidates reports down to its (8 + 4 x expected share of the head)-th largest member (see pf_mloc_for, score.hip)
+    A.pf_mloc = 0;
+#if SDPCUT_LMIN
+    if (tk && pf_k > 0 && h->N > 0) {
+        const double m = 8.0 + 4.0 * (double)pf_k * 256.0 / (double)h->N;
+        A.pf_mloc = m > 256.0 ? 256 : (int)(m + 0.999);
+    }
+#endif
 #define EIG_LAUNCH(KM)                                                   \
     do {                                                                 \
         if (tk) eig_launch<KM, true>(h, A, ev_start, ev_stop);           \

@@ -57,7 +57,7 @@ struct ScoreArgs {
     // the selection never looks below the class.
     TopkWs *tk;
     int tk_mode;           // TK_MODE_FEAS / OPT / STRONG: the kernel's FUSE template argument
-    int64_t pf_k;          // head size of that selection: the streaming prefilter's bound (topk_dev.h) rises to the pf_k-th largest key; 0: no fine histogram
+    int32_t pf_mloc;       // fine histogram of the class (topk_dev.h): a workgroup reports its table down to its pf_mloc-th largest member; 0: off
     // optional: += number of candidates with obj_improve > 0 and lambda_min < -1e-15 (the "strong" class
     // of the combined strategy, cut_select_qp.py:607-613); lets the selection that follows pick its
     // regime on the device.  Needs both flags.
@@ -473,7 +473,7 @@ struct MfmaLds {
     uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
     uint32_t tk_cnt[2];
     uint32_t s_strong;
-    uint32_t pf_tab[PF_BINS];    // (r5) the class members by window code: the streaming prefilter's table (topk_dev.h)
+    uint32_t pf_tab[PF_FBINS / 2];   // (r5) the class members by fine window code, 16-bit counters, two per word (topk_dev.h)
 };
 
 // bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
@@ -566,7 +566,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
 #pragma unroll
-        for (int j = 0; j < PF_BINS / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
+        for (int j = 0; j < PF_FBINS / 2 / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
         __syncthreads();
     }
 
@@ -608,7 +608,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
                 const uint64_t key = key_of(-lam);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-                if (viol) atomicAdd(&pf_tab[pf_wcode(key, pf_b)], 1u);
+                if (viol) { const int f = pf_fcode(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
                 c_viol += viol;
             }
             tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
@@ -837,7 +837,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
                 const uint64_t key = key_of(FUSE == TK_MODE_FEAS ? -lam : obj);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), member);
-                if (member) atomicAdd(&pf_tab[pf_wcode(key, pf_b)], 1u);      // (LDS, no return value: one ds_add per candidate)
+                if (member) { const int f = pf_fcode(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
@@ -876,7 +876,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-        if (A.pf_k > 0) pf_retire(A.tk, pf_tab, A.pf_k);      // (behind the barrier above: the table is complete)
+        if (A.pf_mloc > 0) pf_retire_table(A.tk, pf_tab, A.pf_mloc);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -1270,6 +1270,19 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
     A.tail_nhi = (tiles - lo * W + 3) / 4 * 4;
 }
 
+// How far down its table a workgroup of `per_wg` candidates reports (TopkWs::pf_fine, topk_dev.h): to its m-th largest member,
+// m = 8 + four times its expected share of a head of k out of n_total candidates.  A workgroup with MORE members of the head than
+// that makes the selection fall back to its radix passes (the floor check): for candidates in random order the odds are those of
+// a Poisson variable of mean E reaching 8 + 4 E (E = 2.6 on the 10^6-candidate list: 1e-9 per workgroup).  0: no fine histogram
+// (option off, or a table counter could overflow its 16 bits).
+static int pf_mloc_for(const sdpcut_ctx *h, const ScoreFuse *fuse, int64_t per_wg)
+{
+    if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1) return 0;
+    const double share = (double)fuse->k * (double)per_wg / (double)h->N;
+    const double m = 8.0 + 4.0 * share;
+    return m > 60000.0 ? 60000 : (int)(m + 0.999);
+}
+
 template <int K>
 static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hipEvent_t ev_stop,
                           const ScoreFuse *fuse, int64_t *strong_out, hipStream_t st = nullptr)
@@ -1284,7 +1297,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
     A.tk_mode = fuse ? fuse->mode : 0;
-    A.pf_k = fuse ? fuse->k : 0;
+    A.pf_mloc = 0;      // (set with the grid below)
     A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
     A.net = h->net[K].dev;
     if ((flags & SDPCUT_NN) && !h->net[K].set)
@@ -1305,6 +1318,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
         set_balanced_tail(A, grid);
+        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
@@ -1371,7 +1385,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
         A.eig_out = h->d_eig; A.obj_out = h->d_obj; A.flags = flags;
         A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
         A.tk_mode = f;
-        A.pf_k = fuse ? fuse->k : 0;
+        A.pf_mloc = 0;
         A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
         A.net = h->net[k].dev;
         int grid = grid_for(h, (b.n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
@@ -1380,6 +1394,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
         set_balanced_tail(A, grid);
+        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
         blocks += grid;
         AA.k[i] = k;
         AA.bend[i] = (int32_t)blocks;

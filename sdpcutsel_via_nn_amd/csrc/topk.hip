@@ -159,11 +159,12 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 // Mode COMBAUTO resolved to COMBALL (fewer strong candidates than asked for -- the score kernels
 // counted the STRONG keys): this launch runs its own pass 0 first, histogram in TopkWs::hist_alt.
 #define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
-// (r5) DIRECT: the score / eigenvalue kernels also left the FINE histogram of the class (TopkWs::pf_tab, "streaming prefilter" in
-// topk_dev.h).  Every workgroup resolves from it the window bin e* that holds the k-th largest key; if the members at or above e*
-// fit the sort buffers -- the usual case: 5000 .. 6500 of 10^6 -- they are compacted in ONE pass over the scores and handed to the
-// sort exactly like an early stop of the digit passes: no histogram pass, no grid barrier, no wait (25.8 -> ~12 us on the 10^6-
-// candidate round).  pf_k = 0, a fat bin, or the every-entry-visited regime: the passes below run as before.
+// (r5) DIRECT: the score / eigenvalue kernels also left the FINE histogram of the class (TopkWs::pf_fine, topk_dev.h).  Every
+// workgroup resolves from it the window bin e* that holds the k-th largest key; if e* lies at or above the floor the producers
+// published and the members at or above e* fit the sort buffers -- the usual case: 5000 .. 5100 of 10^6 -- they are compacted in
+// ONE pass over the scores and handed to the sort exactly like an early stop of the digit passes: no histogram pass, no grid
+// barrier, no wait.  pf_k = 0, a workgroup rich in head members, a fat bin, or the every-entry-visited regime: the passes below
+// run as before.
 template <bool ONFLY>
 __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_t k, int64_t chunk, const uint64_t *keys,
                                                                TopkWs *ws, uint64_t *sel_key, uint32_t *sel_idx, int mode,
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
     int last_pass = -1;                             // last digit pass this launch ran (its histogram is still in LDS)
     int p_first = 1;
     bool direct = false;                            // (r5) resolved from the fine table: uniform over the grid
-    __shared__ int pf_e;
+    __shared__ int pf_e, pf_floor_f;
     __shared__ int64_t pf_count;
     if (threadIdx.x == 0) c_above = 0;
     auto key_at = [&](int64_t i) -> uint64_t {
@@ -227,37 +228,43 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
             if (pf_k > 0 && mode != TK_MODE_COMBALL) {
-                // ---- the fine table: bins 4 t .. 4 t + 3 of this thread, suffix sums from the top (plain loads: an earlier launch wrote them)
+                // ---- the fine table: thread t owns fine bins 32 t .. 32 t + 31; suffix sums from the top (plain loads: an earlier
+                // launch wrote them)
                 __shared__ uint32_t pf_wtot[TK_THREADS / 64];
                 const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
-                uint32_t h4[PF_BINS / TK_THREADS], mine4 = 0;
+                constexpr int PER = PF_FBINS / TK_THREADS;
+                uint32_t hf[PER], mine32 = 0;
 #pragma unroll
-                for (int j = 0; j < PF_BINS / TK_THREADS; ++j) { h4[j] = ws->pf_tab[(PF_BINS / TK_THREADS) * t + j]; mine4 += h4[j]; }
-                uint32_t v = mine4;
+                for (int j = 0; j < PER; ++j) { hf[j] = ws->pf_fine[pf_slot(PER * t + j)]; mine32 += hf[j]; }
+                uint32_t floor_c = 0;
+                if (t < PF_FLOOR_REP) floor_c = ws->pf_floor[t][0];
+                for (int off = 8; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)floor_c, off); floor_c = o > floor_c ? o : floor_c; }
+                uint32_t v = mine32;
                 for (int off = 1; off < 64; off <<= 1) {
                     const uint32_t o = (uint32_t)__shfl_down((int)v, off);
                     if (ln + off < 64) v += o;
                 }
                 if (ln == 0) pf_wtot[wv] = v;
-                if (t == 0) { pf_e = -1; pf_count = 0; }
+                if (t == 0) { pf_e = -1; pf_count = 0; pf_floor_f = (int)floor_c * PF_SUB; }
                 __syncthreads();
                 for (int w = wv + 1; w < TK_THREADS / 64; ++w) v += pf_wtot[w];
                 const int64_t need = k < cls ? k : cls;
-                int64_t above = (int64_t)(v - mine4);
+                int64_t above = (int64_t)(v - mine32);
 #pragma unroll
-                for (int j = PF_BINS / TK_THREADS - 1; j >= 0; --j) {
-                    const int64_t here = above + (int64_t)h4[j];
-                    if (need >= 1 && here >= need && above < need) { pf_e = (PF_BINS / TK_THREADS) * t + j; pf_count = here; }      // one bin of one thread
+                for (int j = PER - 1; j >= 0; --j) {
+                    const int64_t here = above + (int64_t)hf[j];
+                    if (need >= 1 && here >= need && above < need) { pf_e = PER * t + j; pf_count = here; }      // one bin of one thread
                     above = here;
                 }
                 __syncthreads();
                 const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
-                // (e* below the bound cannot happen -- at least k members were counted at or above the bound -- but an incomplete bin
-                // must never be trusted: checked)
-                direct = pf_e >= 0 && pf_count <= maxk && (uint32_t)pf_e >= ws->pf_bound;
+                // e* at or above the floor: every workgroup reported every bin from e* up, the counts there are exact and the members
+                // there are all of the class's members with such keys.  (Below the floor some workgroup kept members to itself: the
+                // table undercounts, e* would lie too low -- never trusted.)
+                direct = pf_e >= 0 && pf_e >= pf_floor_f && pf_count <= maxk;
                 if (direct) {
                     const bool all_members = mode == TK_MODE_OPT;
-                    const uint64_t edge = pf_edge(pf_e, pf_base(mode == TK_MODE_FEAS));
+                    const uint64_t edge = pf_fedge(pf_e, pf_base(mode == TK_MODE_FEAS));
                     if (threadIdx.x == 0) {
                         st1.prefix = edge > 0ull || all_members ? edge : 1ull;      // (key 0 = not in the class)
                         st1.need = 1;
@@ -917,7 +924,10 @@ int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words)
     static_assert(sizeof(TopkWs) % 8 == 0, "TopkWs is zeroed in 8-byte words");
     if (!h->d_topk_ws_alt) HIP_TRY(h, hipMalloc(&h->d_topk_ws_alt, sizeof(TopkWs)));
     *ptr = (uint64_t *)h->d_topk_ws_alt;
-    *words = (int)(sizeof(TopkWs) / 8);
+    // (r5) lists too short for the fine histogram (it sits at the end of the struct) zero only what lies in front of it: the epilogue
+    // of a round with a handful of cuts is a handful of workgroups, and every word is a store on its critical path
+    static_assert(offsetof(TopkWs, pf_floor) % 8 == 0 && offsetof(TopkWs, pf_fine) > offsetof(TopkWs, pf_floor), "fine histogram last");
+    *words = (int)((h->N >= SDPCUT_PF_MIN_N ? sizeof(TopkWs) : offsetof(TopkWs, pf_floor)) / 8);
     return 0;
 }
 
@@ -1548,7 +1558,7 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             if (onfly)      // (a measure the mode does not use is never looked at: any readable array of n doubles will do)
                 hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, nullptr, ws,
                                    h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig,
-                                   (int64_t)(h->prefilter ? k : 0), h->d_stats);
+                                   (int64_t)((h->prefilter && h->N >= SDPCUT_PF_MIN_N) ? k : 0), h->d_stats);
             else if (h->coop_launch)      // the runtime guarantees the co-residency (+20 us per launch)
                 HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else

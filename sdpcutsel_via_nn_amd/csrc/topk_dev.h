@@ -33,34 +33,42 @@
 // deep on every cell (+11 us on a 48 us kernel), with 32 the chains are ~120 deep and hidden behind the kernel's tail.
 #define TK_SHREP 32
 
-// ---- streaming prefilter (r5) ---------------------------------------------------------------------------------------
+// ---- the fine histogram of a selection's class (r5) ------------------------------------------------------
 // The LEADING byte of a key image (sign + seven exponent bits) is shared by nearly every member of a class, so the
 // leading-digit histogram the score kernels count (hist_score) only saves the selection its first pass: tk_refine_kernel still
 // ran one or two histogram passes behind grid barriers over all 10^6 keys to find ~5000 of them (25 us of a 387 us round,
 // 75 % of what a feasibility round spends outside its 28 us eigenvalue kernel).  Now the kernels that produce the scores also
-// count the members by the top SIXTEEN bits of the key (sign, exponent, four mantissa bits: 6 % resolution) inside a window of
-// 1024 codes -- one LDS atomic per candidate into a per-workgroup table -- and report the table when they retire.  A retiring
-// workgroup first reads the bound pf_bound and reports only the bins at or above it; every eighth one then scans the global
-// table and raises the bound to the highest bin with at least k members at or above it (counts only grow: the bound is a valid
-// lower bound of the k-th largest key from then on).  Once the first generation of workgroups has reported, a workgroup
-// reports the handful of bins its top 1-2 % of candidates fall into: ~1e5 no-return atomics per 10^6 candidates, none of them
-// on anybody's critical path.  At the end every bin at or above the final bound is EXACT (every workgroup reported all of its
-// members there), and the bin e* of the k-th largest key lies at or above the bound: the selection resolves two digits without
-// reading a key and -- when the members at or above e* fit the sort buffers, the usual case -- compacts them in ONE pass
-// without a grid barrier (tk_refine_kernel, `direct`).  Otherwise (a fat bin: masses of equal keys at a structured LP
-// vertex; the every-entry-visited regime, whose keys are not the ones counted) the passes run as before.
-// Window: codes [base, base + 1023], clamped on both sides (the lowest bin also holds everything below, the highest
-// everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
-#define PF_BINS 1024
-#define PF_UPDATE_EVERY 8      // every n-th retiring workgroup raises the bound
-__device__ __forceinline__ int pf_base(bool feas) { return (feas ? 0xC070 : 0xC170) - (PF_BINS - 1); }
-__device__ __forceinline__ int pf_wcode(uint64_t key, int base)
+// count the members by the top NINETEEN bits of the key (sign, exponent, seven mantissa bits: 0.8 % resolution) inside a window
+// of 8192 codes, per workgroup in LDS, and report -- when the workgroup retires -- only the TOP of their table: the bins down
+// to the coarse bin (8 fine bins) that holds their m-th largest member, m a few times the workgroup's expected share of the
+// head (pf_mloc).  A workgroup also publishes the lowest coarse bin it reported (pf_floor, a maximum over workgroups).  Every
+// fine bin at or above the floor is then EXACT.  The selection finds the fine bin e* of the k-th largest key in the global
+// table; if e* lies at or above the floor -- no workgroup held more than m members of the head: always, unless the list is
+// sorted by score -- and the members at or above e* fit the sort buffers, it compacts them in ONE pass over the scores without
+// reading a key twice, without a histogram pass, without a grid barrier (tk_refine_kernel, `direct`).  Otherwise (a workgroup
+// rich in head members; a fat bin: masses of equal keys at a structured LP vertex; the every-entry-visited regime, whose keys
+// are not the ones counted) the radix passes run as before: same result either way.
+// What it costs the producers: one LDS atomic per candidate, ~100 instructions per thread when a workgroup retires (1 % of the
+// score kernel), and ~20-30 no-return device atomics per workgroup spread over a few hundred addresses in different cache
+// lines (profiles/r05_ubench_atomics.txt: device atomics serialise per ADDRESS at 11 ns and per 128-B line at 1.6 ns; the first
+// version of this -- every member reported at 16-bit resolution into 4 KB -- queued 3e5 atomics on ~25 hot words of one or two
+// lines and cost the eigenvalue kernel 200 us).
+// Window: coarse codes (top 16 bits) [base, base + 1023] x 8 sub-bins, clamped on both sides (the lowest bin also holds
+// everything below, the highest everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
+#define PF_CBINS 1024                   // coarse bins (top 16 key bits)
+#define PF_SUB 8                        // fine bins per coarse bin (3 more bits)
+#define PF_FBINS (PF_CBINS * PF_SUB)    // 8192
+#define PF_FLOOR_REP 16                 // replicas of the floor word, one 128-B line each
+__device__ __forceinline__ int pf_base(bool feas) { return (feas ? 0xC070 : 0xC170) - (PF_CBINS - 1); }
+__device__ __forceinline__ int pf_fcode(uint64_t key, int base)
 {
-    const int c = (int)(uint32_t)(key >> 48) - base;
-    return c < 0 ? 0 : (c > PF_BINS - 1 ? PF_BINS - 1 : c);
+    const int c = (int)(uint32_t)(key >> 45) - base * PF_SUB;
+    return c < 0 ? 0 : (c > PF_FBINS - 1 ? PF_FBINS - 1 : c);
 }
-// lowest key of window bin e (0: everything)
-__device__ __forceinline__ uint64_t pf_edge(int e, int base) { return e <= 0 ? 0ull : (uint64_t)(uint32_t)(base + e) << 48; }
+// lowest key of fine bin f (0: everything)
+__device__ __forceinline__ uint64_t pf_fedge(int f, int base) { return f <= 0 ? 0ull : (uint64_t)(uint32_t)(base * PF_SUB + f) << 45; }
+// word of fine bin f in the global table: consecutive bins in consecutive 128-B lines (a hot run of bins = as many lines)
+__device__ __forceinline__ int pf_slot(int f) { return (f & 255) * 32 + (f >> 8); }
 
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
@@ -100,10 +108,10 @@ struct TopkWs {
     int64_t viol_rep[TK_SHREP];           // violated / positive candidates counted by the same kernels, replicated by workgroup:
     int64_t pos_rep[TK_SHREP];            // ONE counter each would queue thousands of retiring workgroups on one address (~15 ns
                                           // apiece: 58 us for the eigenvalue kernel's 3907 workgroups -- longer than the kernel runs)
-    // (r5) the FINE histogram the score / eigenvalue kernels leave for the selection (see "streaming prefilter" below):
-    uint32_t pf_tab[PF_BINS];             // class members by window code (the top 16 bits of the key, clamped into a 1024-bin window)
-    uint32_t pf_bound;                    // bins below this one are no longer reported: at least k members lie at or above it
-    uint32_t pf_pad_;
+    // (r5) the FINE histogram the score / eigenvalue kernels leave for the selection (see above); LAST in the struct: lists too
+    // short for it zero only what lies in front (offsetof(TopkWs, pf_floor))
+    uint32_t pf_floor[PF_FLOOR_REP][32];  // max over workgroups of the lowest COARSE bin they reported (replicas in separate lines)
+    uint32_t pf_fine[PF_FBINS];           // class members by fine window code, word pf_slot(f)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -152,39 +160,96 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
     if ((rem >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
 }
 
-// ---- streaming prefilter: device side of the producers (score.hip, eig.hip) ------------------------------------------
-// Report this workgroup's table (LDS, PF_BINS cells, complete: call behind a workgroup barrier) and, for every
-// PF_UPDATE_EVERY-th workgroup, raise the bound.  256 threads.
-static __device__ void pf_retire(TopkWs *ws, const uint32_t *tab, int64_t k)
+// ---- fine histogram: device side of the producers (score.hip, eig.hip) -------------------------------------------------
+// Suffix sums over the 256 threads of a workgroup: every thread passes the total of the bins it owns (thread t owns the bins
+// just above thread t - 1's), returns the total of all threads ABOVE it.  Two barriers.
+static __device__ uint32_t pf_above(uint32_t mine)
 {
-    const uint32_t bound = ld_u32(&ws->pf_bound);
-#pragma unroll
-    for (int j = 0; j < PF_BINS / 256; ++j) {
-        const int bin = (int)threadIdx.x + 256 * j;
-        const uint32_t v = tab[bin];
-        if (v && (uint32_t)bin >= bound) __hip_atomic_fetch_add(&ws->pf_tab[bin], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if ((blockIdx.x % PF_UPDATE_EVERY) != 0 || threadIdx.x >= 64) return;      // one wave of every n-th workgroup
-    // lane l owns bins 16 l .. 16 l + 15; suffix sums from the top
-    const int lane = (int)threadIdx.x;
-    uint32_t h[PF_BINS / 64];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < PF_BINS / 64; ++j) { h[j] = ld_u32(&ws->pf_tab[(PF_BINS / 64) * lane + j]); mine += h[j]; }
-    uint32_t v = mine;      // inclusive suffix sum over the lanes
+    __shared__ uint32_t wtot[4];
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t v = mine;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_down((int)v, off);
-        if (lane + off < 64) v += o;
+        if (ln + off < 64) v += o;
     }
-    int64_t above = (int64_t)(v - mine);
-    int found = -1;
+    __syncthreads();      // (wtot of an earlier call has been read)
+    if (ln == 0) wtot[wv] = v;
+    __syncthreads();
+    for (int w = wv + 1; w < 4; ++w) v += wtot[w];
+    return v - mine;
+}
+
+__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_c)
+{
+    if (floor_c > 0)
+        __hip_atomic_fetch_max(&ws->pf_floor[blockIdx.x % PF_FLOOR_REP][0], (uint32_t)floor_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Score kernels: the workgroup's table `tab` (LDS, PF_FBINS counters of 16 bits, two per word, complete: call behind a
+// workgroup barrier; 256 threads).  Thread t owns fine bins 32 t .. 32 t + 31 = coarse bins 4 t .. 4 t + 3.
+static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc)
+{
+    __shared__ int s_floor;
+    const int t = threadIdx.x;
+    uint32_t w[16];
 #pragma unroll
-    for (int j = PF_BINS / 64 - 1; j >= 0; --j) {
-        const int64_t here = above + (int64_t)h[j];
-        if (here >= k && above < k) found = (PF_BINS / 64) * lane + j;      // exactly one bin of one lane (if the table holds k members at all)
+    for (int j = 0; j < 16; ++j) w[j] = tab[16 * t + j];
+    uint32_t hc[4], mine = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a += (w[4 * c + j] & 0xffffu) + (w[4 * c + j] >> 16);
+        hc[c] = a;
+        mine += a;
+    }
+    if (t == 0) s_floor = 0;
+    uint32_t above = pf_above(mine);      // (its barriers also order the store above)
+    // the coarse bin that holds the workgroup's mloc-th largest member (none: fewer members than that -- everything is reported)
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+        const uint32_t here = above + hc[c];
+        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) s_floor = 4 * t + c;      // one bin of one thread
         above = here;
     }
-    if (found > 0) __hip_atomic_fetch_max(&ws->pf_bound, (uint32_t)found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int floor_c = s_floor;
+    if (t == 0) pf_publish_floor(ws, floor_c);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (4 * t + c < floor_c || hc[c] == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[4 * c + j] & 0xffffu, hi = w[4 * c + j] >> 16;
+            const int f = 32 * t + 8 * c + 2 * j;
+            if (lo) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (hi) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f + 1)], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Eigenvalue kernel (a thread = a candidate of the tile, its key in a register): `ctab` = the tile's COARSE table (LDS, PF_CBINS
+// words, complete: behind a barrier); members at or above the tile's floor are reported one by one.  Clears the table.
+static __device__ void pf_retire_keys(TopkWs *ws, uint32_t *ctab, int mloc, bool member, int fcode)
+{
+    __shared__ int s_floor;
+    const int t = threadIdx.x;
+    uint32_t hc[4], mine = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { hc[c] = ctab[4 * t + c]; ctab[4 * t + c] = 0; mine += hc[c]; }
+    if (t == 0) s_floor = 0;
+    uint32_t above = pf_above(mine);
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+        const uint32_t here = above + hc[c];
+        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) s_floor = 4 * t + c;
+        above = here;
+    }
+    __syncthreads();
+    const int floor_c = s_floor;
+    if (t == 0) pf_publish_floor(ws, floor_c);
+    if (member && (fcode >> 3) >= floor_c)
+        __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(fcode)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].

@@ -137,7 +137,9 @@ def test_direct_selection_equals_the_radix_passes(count, sel):
             a, b, taken = _round_ab(sc, strat, sel, wl["vars_values"])
             _same_round(a, b)
             assert a["idx"].shape[0] == sel
-            if count >= 10 ** 6:      # (a head that is a large share of a short list can have its threshold in a fat bin: the passes run)
+            # (a head that is a large share of a short list can have its threshold in a fat bin or below the floor, a head of
+            # exactly the sort buffers' size cannot have a superset that fits: the passes run)
+            if count >= 10 ** 6 and sel <= 5000:
                 assert taken == 1, (strat, taken)
         assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
     finally:
