@@ -664,6 +664,8 @@ def main():
     ap.add_argument("--no-auto-regime", action="store_true",
                     help="A/B: combined strategy assumes the common regime, the host repeats the selection otherwise")
     ap.add_argument("--no-fused-tail", action="store_true", help="A/B: one launch per selection pass")
+    ap.add_argument("--no-prefilter", action="store_true",
+                    help="A/B: the score kernels do not count the fine histogram of the class; the selection runs its radix passes (rounds 2-4)")
     ap.add_argument("--no-pinned-point", action="store_true",
                     help="A/B (c4 configs): hand the LP point over in an ordinary host array instead of the handle's pinned buffer")
     ap.add_argument("--two-calls", action="store_true", help="A/B: sdpcut_set_point + sdpcut_select_round_view instead of sdpcut_round_view")
@@ -751,6 +753,8 @@ def main():
             sc.set_option(_capi.OPT_FUSED_TAIL, 0)
         if args.coop:
             sc.set_option(_capi.OPT_COOP_LAUNCH, 1)
+        if args.no_prefilter:
+            sc.set_option(_capi.OPT_PREFILTER, 0)
         sc.set_option(_capi.OPT_KERNEL, kernel_opt)
         sc.set_network(k, *networks.load_network(k))
         Q_arr, vv, _ = synthetic.make_instance(nb_vars, seed=7)      # one LP point and one objective for the whole job

@@ -115,9 +115,11 @@ enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, S
  * cut_select_qp.py:601 under :625 -- with two more radix selections; until round 3 these rounds were fallbacks.
  * SDPCUT_STAT_DIRECT_SELECTIONS (r5) = selections resolved from the fine histogram the score kernels leave (no digit pass, no grid
  *   barrier: SDPCUT_OPT_PREFILTER); the others ran the radix passes (short lists, masses of equal keys at the threshold, the
- *   every-entry-visited regime).  Read from the device: the call waits for the handle's stream.  Same results either way. */
+ *   every-entry-visited regime).  Read from the device: the call waits for the handle's stream.  Same results either way.
+ * SDPCUT_STAT_PF_BIN / _PF_FLOOR / _PF_COUNT: what the last selection that looked at the fine histogram found there -- the fine bin of
+ *   the k-th largest key (-1: none), the floor the producers published (fine bins), the members at or above that bin.  Diagnostics. */
 enum { SDPCUT_STAT_ROUNDS = 1, SDPCUT_STAT_SELECT_FALLBACKS = 2, SDPCUT_STAT_SCORED = 3, SDPCUT_STAT_TIE_SPLITS = 4,
-       SDPCUT_STAT_DIRECT_SELECTIONS = 5 };
+       SDPCUT_STAT_DIRECT_SELECTIONS = 5, SDPCUT_STAT_PF_BIN = 6, SDPCUT_STAT_PF_FLOOR = 7, SDPCUT_STAT_PF_COUNT = 8 };
 int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value);
 
 /* Maximum sub-problem size (assert dim <= 5, cut_select_qp.py:93) */

@@ -20,7 +20,7 @@ PART_STRONG = 104
 PART_COMBALL = 105
 KERNEL_MFMA, KERNEL_SIMPLE, KERNEL_VALU = 0, 1, 2
 OPT_KERNEL, OPT_TIMING, OPT_FUSE_KEYS, OPT_AUTO_REGIME, OPT_FUSED_TAIL, OPT_COOP_LAUNCH, OPT_EIG_KERNEL, OPT_STREAM_PRIORITY, OPT_SIDE_STREAMS, OPT_ONE_LAUNCH, OPT_PREFILTER = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
-STAT_ROUNDS, STAT_SELECT_FALLBACKS, STAT_SCORED, STAT_TIE_SPLITS, STAT_DIRECT_SELECTIONS = 1, 2, 3, 4, 5
+STAT_ROUNDS, STAT_SELECT_FALLBACKS, STAT_SCORED, STAT_TIE_SPLITS, STAT_DIRECT_SELECTIONS, STAT_PF_BIN, STAT_PF_FLOOR, STAT_PF_COUNT = 1, 2, 3, 4, 5, 6, 7, 8
 ROW_LD = 20
 
 _c = ctypes

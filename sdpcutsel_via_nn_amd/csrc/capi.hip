@@ -294,10 +294,13 @@ int sdpcut_get_stat(sdpcut_handle h, int which, int64_t *value)
     case SDPCUT_STAT_SELECT_FALLBACKS: *value = h->stat_fallbacks; return SDPCUT_OK;
     case SDPCUT_STAT_SCORED: *value = h->have_point ? (int64_t)h->scored : 0; return SDPCUT_OK;
     case SDPCUT_STAT_TIE_SPLITS: *value = h->stat_tie_splits; return SDPCUT_OK;
-    case SDPCUT_STAT_DIRECT_SELECTIONS: {
+    case SDPCUT_STAT_DIRECT_SELECTIONS:
+    case SDPCUT_STAT_PF_BIN:
+    case SDPCUT_STAT_PF_FLOOR:
+    case SDPCUT_STAT_PF_COUNT: {
         unsigned long long v = 0;
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipMemcpyAsync(&v, h->d_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(&v, h->d_stats + (which - SDPCUT_STAT_DIRECT_SELECTIONS), sizeof(v), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, sdpcut_sync(h));
         *value = (int64_t)v;
         return SDPCUT_OK;

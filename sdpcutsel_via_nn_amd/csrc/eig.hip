@@ -33,7 +33,7 @@ struct EigArgs {
     int64_t L;
     double *eig_out;
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
-    int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): a tile reports its members down to its pf_mloc-th largest; 0: off
+    int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): every tile reports its largest members (pf_retire_keys); 0: off
 };
 
 // ---- re-packing the lanes that have not converged ------------------------------------------------------------
@@ -78,11 +78,7 @@ __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t o
         const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
         const uint64_t key = key_of(-lam);
         hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-        if (pf_code) {      // (r5) the tile's coarse table sits behind the histogram; the fine code stays in a register until the tile retires
-            const int f = pf_fcode(key, pf_base(true));
-            *pf_code = viol ? f : -1;
-            if (viol && A.pf_mloc > 0) atomicAdd(&tk_hist[256 + (f >> 3)], 1u);
-        }
+        if (pf_code) *pf_code = viol ? pf_fcode(key, pf_base(true)) : -1;      // (r5) fine histogram of the class: reported when the tile retires
         c_viol += viol;
     }
 }
@@ -91,7 +87,7 @@ __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t o
 // cnt = this tile's packed-lane counter (zero on entry)
 template <int K, bool FUSE>
 __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K], int32_t out_idx, bool valid, double *s_state,
-                                         int32_t *s_out, uint32_t *cnt, uint32_t *tk_hist, uint32_t &c_viol)
+                                         int32_t *s_out, uint32_t *cnt, uint32_t *tk_hist, uint32_t &c_viol, int par)
 {
     using P = EigPack<K>;
     constexpr int D = P::D;
@@ -103,10 +99,7 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
     int pf_code = -1;
     eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_code);
     if constexpr (FUSE) {
-        if (A.pf_mloc > 0) {      // uniform: the tile reports the top of its table (two barriers; every thread of the workgroup is here)
-            __syncthreads();
-            pf_retire_keys(A.tk, tk_hist + 256, A.pf_mloc, pf_code >= 0, pf_code);
-        }
+        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 4 * par), pf_code);      // uniform; one barrier (every thread of the workgroup is here)
     }
     (void)s_state; (void)s_out; (void)cnt;
     return;
@@ -183,7 +176,7 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
             load_index_set<K>(s_nxt, A.set[K], n, cc);
             orig_nxt = A.orig[K][cc];
         }
-        eig_tile<K, FUSE>(A, s_cur, out_idx, valid, s_state, s_out, &s_packed[par], tk_hist, c_viol);
+        eig_tile<K, FUSE>(A, s_cur, out_idx, valid, s_state, s_out, &s_packed[par], tk_hist, c_viol, par);
         if constexpr (!SDPCUT_LMIN && SDPCUT_EIG_REPACK && EigPack<K>::CAP > 0) {
             // the next tile counts into the other word (zero since the barrier of the tile before this one); this tile's is
             // cleared behind the barrier that ends its use, in front of the barrier of the next tile
@@ -208,15 +201,14 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256 + (FUSE ? PF_CBINS : 0)];      // leading-digit histogram | (r5) coarse table of the current tile (topk_dev.h)
+    __shared__ uint32_t tk_hist[256 + 8];      // leading-digit histogram | (r5) the four waves' third largest fine codes of the current / the next tile
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];
     __shared__ uint32_t s_packed[2];      // packed-lane counters of the current / the next tile
     if (threadIdx.x < 2) s_packed[threadIdx.x] = 0;
     if constexpr (FUSE) {
-#pragma unroll
-        for (int j = 0; j < 1 + PF_CBINS / 256; ++j) tk_hist[threadIdx.x + 256 * j] = 0;
+        tk_hist[threadIdx.x] = 0;
         if (threadIdx.x == 0) tk_cnt = 0;
     }
     __syncthreads();
@@ -278,13 +270,10 @@ int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_
     A.set[0] = A.set[1] = nullptr; A.orig[0] = A.orig[1] = nullptr; A.n[0] = A.n[1] = 0; A.tile_end[0] = A.tile_end[1] = acc;
     if (kmax == 0) return 0;
     A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk;
-    // a tile of 256 candidates reports down to its (8 + 4 x expected share of the head)-th largest member (see pf_mloc_for, score.hip)
+    // fine histogram of the class (topk_dev.h: pf_retire_keys): the Householder + Laguerre path only (one value per lane and tile)
     A.pf_mloc = 0;
 #if SDPCUT_LMIN
-    if (tk && pf_k > 0 && h->N > 0) {
-        const double m = 8.0 + 4.0 * (double)pf_k * 256.0 / (double)h->N;
-        A.pf_mloc = m > 256.0 ? 256 : (int)(m + 0.999);
-    }
+    if (tk && pf_k > 0) A.pf_mloc = 3;
 #endif
 #define EIG_LAUNCH(KM)                                                   \
     do {                                                                 \

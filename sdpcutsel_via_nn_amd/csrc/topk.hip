@@ -262,6 +262,11 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 // there are all of the class's members with such keys.  (Below the floor some workgroup kept members to itself: the
                 // table undercounts, e* would lie too low -- never trusted.)
                 direct = pf_e >= 0 && pf_e >= pf_floor_f && pf_count <= maxk;
+                if (d_stats && blockIdx.x == 0 && threadIdx.x == 0) {      // what the last selection saw (sdpcut_get_stat, diagnostics)
+                    d_stats[1] = (unsigned long long)(long long)pf_e;
+                    d_stats[2] = (unsigned long long)(long long)pf_floor_f;
+                    d_stats[3] = (unsigned long long)pf_count;
+                }
                 if (direct) {
                     const bool all_members = mode == TK_MODE_OPT;
                     const uint64_t edge = pf_fedge(pf_e, pf_base(mode == TK_MODE_FEAS));

@@ -39,10 +39,11 @@
 // ran one or two histogram passes behind grid barriers over all 10^6 keys to find ~5000 of them (25 us of a 387 us round,
 // 75 % of what a feasibility round spends outside its 28 us eigenvalue kernel).  Now the kernels that produce the scores also
 // count the members by the top NINETEEN bits of the key (sign, exponent, seven mantissa bits: 0.8 % resolution) inside a window
-// of 8192 codes, per workgroup in LDS, and report -- when the workgroup retires -- only the TOP of their table: the bins down
-// to the coarse bin (8 fine bins) that holds their m-th largest member, m a few times the workgroup's expected share of the
-// head (pf_mloc).  A workgroup also publishes the lowest coarse bin it reported (pf_floor, a maximum over workgroups).  Every
-// fine bin at or above the floor is then EXACT.  The selection finds the fine bin e* of the k-th largest key in the global
+// of 8192 codes and report only the TOP of what they saw: a score workgroup keeps a table in LDS and reports, when it retires, the
+// bins down to the coarse bin (8 fine bins) that holds its m-th largest member, m a few times its expected share of the head
+// (pf_mloc); a tile of the eigenvalue kernel reports the members down to the smallest of its four waves' third largest codes.
+// Each also publishes the lowest bin it reported (pf_floor, a maximum over all of them).  Every fine bin at or above the floor
+// is then EXACT.  The selection finds the fine bin e* of the k-th largest key in the global
 // table; if e* lies at or above the floor -- no workgroup held more than m members of the head: always, unless the list is
 // sorted by score -- and the members at or above e* fit the sort buffers, it compacts them in ONE pass over the scores without
 // reading a key twice, without a histogram pass, without a grid barrier (tk_refine_kernel, `direct`).  Otherwise (a workgroup
@@ -110,7 +111,7 @@ struct TopkWs {
                                           // apiece: 58 us for the eigenvalue kernel's 3907 workgroups -- longer than the kernel runs)
     // (r5) the FINE histogram the score / eigenvalue kernels leave for the selection (see above); LAST in the struct: lists too
     // short for it zero only what lies in front (offsetof(TopkWs, pf_floor))
-    uint32_t pf_floor[PF_FLOOR_REP][32];  // max over workgroups of the lowest COARSE bin they reported (replicas in separate lines)
+    uint32_t pf_floor[PF_FLOOR_REP][32];  // max over workgroups of the lowest FINE bin they reported (replicas in separate lines)
     uint32_t pf_fine[PF_FBINS];           // class members by fine window code, word pf_slot(f)
 };
 
@@ -161,51 +162,36 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
 }
 
 // ---- fine histogram: device side of the producers (score.hip, eig.hip) -------------------------------------------------
-// Suffix sums over the 256 threads of a workgroup: every thread passes the total of the bins it owns (thread t owns the bins
-// just above thread t - 1's), returns the total of all threads ABOVE it.  Two barriers.
-static __device__ uint32_t pf_above(uint32_t mine)
+// the floor is published in FINE bins: a maximum over the reporting units (replicas in separate cache lines)
+__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f)
+{
+    if (floor_f > 0)
+        __hip_atomic_fetch_max(&ws->pf_floor[blockIdx.x % PF_FLOOR_REP][0], (uint32_t)floor_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Score kernels: the workgroup's tables (LDS, 16-bit counters, two per word; complete: call behind a workgroup barrier; 256
+// threads): `ctab` PF_CBINS coarse counters, `ftab` PF_FBINS fine ones.  Thread t owns coarse bins 4 t .. 4 t + 3 (fine bins
+// 32 t .. 32 t + 31).  Reports the fine bins of every coarse bin down to the one that holds the workgroup's mloc-th largest
+// member (fewer members than that: everything).  ~40 instructions and three barriers per thread; the few threads at the top
+// of the table also read their fine counters and issue the atomics.
+static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const uint32_t *ftab, int mloc)
 {
     __shared__ uint32_t wtot[4];
-    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t v = mine;
+    __shared__ int s_floor;
+    const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
+    const uint32_t w0 = ctab[2 * t], w1 = ctab[2 * t + 1];
+    const uint32_t hc[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+    const uint32_t mine = hc[0] + hc[1] + hc[2] + hc[3];
+    uint32_t v = mine;      // suffix sums: thread t's bins lie above thread t - 1's
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_down((int)v, off);
         if (ln + off < 64) v += o;
     }
-    __syncthreads();      // (wtot of an earlier call has been read)
     if (ln == 0) wtot[wv] = v;
+    if (t == 0) s_floor = 0;
     __syncthreads();
     for (int w = wv + 1; w < 4; ++w) v += wtot[w];
-    return v - mine;
-}
-
-__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_c)
-{
-    if (floor_c > 0)
-        __hip_atomic_fetch_max(&ws->pf_floor[blockIdx.x % PF_FLOOR_REP][0], (uint32_t)floor_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Score kernels: the workgroup's table `tab` (LDS, PF_FBINS counters of 16 bits, two per word, complete: call behind a
-// workgroup barrier; 256 threads).  Thread t owns fine bins 32 t .. 32 t + 31 = coarse bins 4 t .. 4 t + 3.
-static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc)
-{
-    __shared__ int s_floor;
-    const int t = threadIdx.x;
-    uint32_t w[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = tab[16 * t + j];
-    uint32_t hc[4], mine = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        uint32_t a = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a += (w[4 * c + j] & 0xffffu) + (w[4 * c + j] >> 16);
-        hc[c] = a;
-        mine += a;
-    }
-    if (t == 0) s_floor = 0;
-    uint32_t above = pf_above(mine);      // (its barriers also order the store above)
-    // the coarse bin that holds the workgroup's mloc-th largest member (none: fewer members than that -- everything is reported)
+    uint32_t above = v - mine;
 #pragma unroll
     for (int c = 3; c >= 0; --c) {
         const uint32_t here = above + hc[c];
@@ -214,13 +200,15 @@ static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc
     }
     __syncthreads();
     const int floor_c = s_floor;
-    if (t == 0) pf_publish_floor(ws, floor_c);
+    if (t == 0) pf_publish_floor(ws, floor_c * PF_SUB);
+    if (4 * t + 3 < floor_c || mine == 0) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (4 * t + c < floor_c || hc[c] == 0) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = w[4 * c + j] & 0xffffu, hi = w[4 * c + j] >> 16;
+            const uint32_t w = ftab[16 * t + 4 * c + j];
+            const uint32_t lo = w & 0xffffu, hi = w >> 16;
             const int f = 32 * t + 8 * c + 2 * j;
             if (lo) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (hi) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f + 1)], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -228,27 +216,31 @@ static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc
     }
 }
 
-// Eigenvalue kernel (a thread = a candidate of the tile, its key in a register): `ctab` = the tile's COARSE table (LDS, PF_CBINS
-// words, complete: behind a barrier); members at or above the tile's floor are reported one by one.  Clears the table.
-static __device__ void pf_retire_keys(TopkWs *ws, uint32_t *ctab, int mloc, bool member, int fcode)
+// Eigenvalue kernel (a thread = a candidate of the tile, its fine code in a register: -1 = not in the class): no table at all.
+// Every wave finds the third largest DISTINCT code among its lanes; the tile's floor is the smallest of the four, and every
+// member at or above it is reported by its own lane: at least three per wave, typically 15-25 per tile.  The tile fails the
+// selection's floor check only if EVERY one of its waves holds three members of the head (3e-10 per tile on 10^6 candidates in
+// random order).  One barrier; s_w3: four words of LDS.
+static __device__ void pf_retire_keys(TopkWs *ws, int *s_w3, int fcode)
 {
-    __shared__ int s_floor;
-    const int t = threadIdx.x;
-    uint32_t hc[4], mine = 0;
+    int m = fcode;      // wave maximum, three times, each below the previous one
+    int third = -1;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { hc[c] = ctab[4 * t + c]; ctab[4 * t + c] = 0; mine += hc[c]; }
-    if (t == 0) s_floor = 0;
-    uint32_t above = pf_above(mine);
-#pragma unroll
-    for (int c = 3; c >= 0; --c) {
-        const uint32_t here = above + hc[c];
-        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) s_floor = 4 * t + c;
-        above = here;
+    for (int r = 0; r < 3; ++r) {
+        int v = m;
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+        third = v;
+        m = m >= v ? -1 : m;
     }
+    if ((threadIdx.x & 63) == 0) s_w3[threadIdx.x >> 6] = third;
     __syncthreads();
-    const int floor_c = s_floor;
-    if (t == 0) pf_publish_floor(ws, floor_c);
-    if (member && (fcode >> 3) >= floor_c)
+    int fl = s_w3[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) fl = s_w3[w] < fl ? s_w3[w] : fl;
+    // (a wave with fewer than three distinct codes reports everything it has: third = -1 -> the tile's floor is 0)
+    fl = fl < 0 ? 0 : fl;
+    if (threadIdx.x == 0) pf_publish_floor(ws, fl);
+    if (fcode >= fl && fcode >= 0)
         __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(fcode)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -107,6 +107,7 @@ def _round_ab(sc, strat, sel, vv):
         after = sc.get_stat(_capi.STAT_DIRECT_SELECTIONS)
         if on:
             taken = after - before
+            _round_ab.last = tuple(sc.get_stat(w) for w in (_capi.STAT_PF_BIN, _capi.STAT_PF_FLOOR, _capi.STAT_PF_COUNT))
         else:
             assert after == before
     sc.set_option(_capi.OPT_PREFILTER, 1)
@@ -195,7 +196,8 @@ def test_direct_selection_on_a_real_mixed_cover(oracle):
             a, b, taken = _round_ab(sc, strat, 5000, np.ascontiguousarray(g["r%02d_vars" % r]))
             _same_round(a, b)
             assert np.array_equal(a["idx"], g["r%02d_ids" % r].astype(np.int64)) or r == 2
+            print("round", r, "strategy", strat, "direct", taken, "fine bin / floor / members", _round_ab.last)
             if r in (4, 8):
-                assert taken == 1, (r, strat, taken)
+                assert taken == 1, (r, strat, taken, _round_ab.last)
     finally:
         sc.close()
