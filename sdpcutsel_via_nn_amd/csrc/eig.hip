@@ -99,7 +99,7 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
     int pf_code = -1;
     eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_code);
     if constexpr (FUSE) {
-        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 4 * par), pf_code);      // uniform; one barrier (every thread of the workgroup is here)
+        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 8 * par), pf_code);      // uniform; one barrier (every thread of the workgroup is here)
     }
     (void)s_state; (void)s_out; (void)cnt;
     return;
@@ -201,7 +201,7 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256 + 8];      // leading-digit histogram | (r5) the four waves' third largest fine codes of the current / the next tile
+    __shared__ uint32_t tk_hist[256 + 16];      // leading-digit histogram | (r5) the four waves' third largest and largest fine codes of the current / the next tile
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];

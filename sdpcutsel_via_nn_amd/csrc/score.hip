@@ -1282,15 +1282,17 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
 }
 
 // How far down its table a workgroup of `per_wg` candidates reports (TopkWs::pf_fine, topk_dev.h): to its m-th largest member,
-// m = 8 + four times its expected share of a head of k out of n_total candidates.  A workgroup with MORE members of the head than
-// that makes the selection fall back to its radix passes (the floor check): for candidates in random order the odds are those of
-// a Poisson variable of mean E reaching 8 + 4 E (E = 2.6 on the 10^6-candidate list: 1e-9 per workgroup).  0: no fine histogram
-// (option off, or a table counter could overflow its 16 bits).
+// m = 24 + eight times its expected share E of a head of k out of n_total candidates.  A workgroup with MORE members of the head
+// than that makes the selection fall back to its radix passes (the floor check).  For candidates in random order that never
+// happens (a Poisson variable of mean 2.6 reaching 45); real covers are enumerated index set by index set, neighbours share
+// variables and scores, and the head clusters: spar125-075-1 dim 4 has workgroups with > 18 of the 5000 (8 + 4 E failed there).
+// Reporting more costs little: ~45 atomics per workgroup over a few hundred addresses.  0: no fine histogram (option off, or
+// a table counter could overflow its 16 bits).
 static int pf_mloc_for(const sdpcut_ctx *h, const ScoreFuse *fuse, int64_t per_wg)
 {
     if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1) return 0;
     const double share = (double)fuse->k * (double)per_wg / (double)h->N;
-    const double m = 8.0 + 4.0 * share;
+    const double m = 24.0 + 8.0 * share;
     return m > 60000.0 ? 60000 : (int)(m + 0.999);
 }
 

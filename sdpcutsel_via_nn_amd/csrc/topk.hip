@@ -228,33 +228,49 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
             if (pf_k > 0 && mode != TK_MODE_COMBALL) {
-                // ---- the fine table: thread t owns fine bins 32 t .. 32 t + 31; suffix sums from the top (plain loads: an earlier
-                // launch wrote them)
-                __shared__ uint32_t pf_wtot[TK_THREADS / 64];
+                // ---- the fine table, read from the highest reported bin DOWN to the floor (typically 300-600 of the 8192 bins: two
+                // loads per thread instead of 32; plain loads: an earlier launch wrote them).  Thread t of round r owns bin
+                // top - (256 r + t): cumulative counts in thread order are suffix sums from the top.
+                constexpr int PF_MAXR = 8;
+                __shared__ uint32_t pf_wtot[PF_MAXR][TK_THREADS / 64];
                 const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
-                constexpr int PER = PF_FBINS / TK_THREADS;
-                uint32_t hf[PER], mine32 = 0;
-#pragma unroll
-                for (int j = 0; j < PER; ++j) { hf[j] = ws->pf_fine[pf_slot(PER * t + j)]; mine32 += hf[j]; }
-                uint32_t floor_c = 0;
-                if (t < PF_FLOOR_REP) floor_c = ws->pf_floor[t][0];
-                for (int off = 8; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)floor_c, off); floor_c = o > floor_c ? o : floor_c; }
-                uint32_t v = mine32;
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_down((int)v, off);
-                    if (ln + off < 64) v += o;
+                uint32_t fl = 0, tp = 0;
+                if (ln < PF_FLOOR_REP) { fl = ws->pf_floor[ln][0]; tp = ws->pf_floor[ln][1]; }
+                for (int off = 8; off > 0; off >>= 1) {
+                    const uint32_t a = (uint32_t)__shfl_xor((int)fl, off), b = (uint32_t)__shfl_xor((int)tp, off);
+                    fl = a > fl ? a : fl;
+                    tp = b > tp ? b : tp;
                 }
-                if (ln == 0) pf_wtot[wv] = v;
-                if (t == 0) { pf_e = -1; pf_count = 0; pf_floor_f = (int)floor_c * PF_SUB; }
-                __syncthreads();
-                for (int w = wv + 1; w < TK_THREADS / 64; ++w) v += pf_wtot[w];
-                const int64_t need = k < cls ? k : cls;
-                int64_t above = (int64_t)(v - mine32);
+                const int floor_f = __shfl((int)fl, 0), top_f = __shfl((int)tp, 0);      // uniform over the grid
+                // bins floor .. top, the highest 2048 of them at most (a k-th largest key further down: the passes run)
+                const int rounds = (top_f - floor_f + 256) / 256 < PF_MAXR ? (top_f - floor_f + 256) / 256 : PF_MAXR;
+                uint32_t hv[PF_MAXR], cum[PF_MAXR];
 #pragma unroll
-                for (int j = PER - 1; j >= 0; --j) {
-                    const int64_t here = above + (int64_t)hf[j];
-                    if (need >= 1 && here >= need && above < need) { pf_e = PER * t + j; pf_count = here; }      // one bin of one thread
-                    above = here;
+                for (int r = 0; r < PF_MAXR; ++r) {
+                    const int b = top_f - (256 * r + t);
+                    hv[r] = (r < rounds && b >= floor_f) ? ws->pf_fine[pf_slot(b)] : 0u;
+                }
+#pragma unroll
+                for (int r = 0; r < PF_MAXR; ++r) {
+                    uint32_t v = hv[r];      // inclusive prefix sum over the lanes
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t o = (uint32_t)__shfl_up((int)v, off);
+                        if (ln >= off) v += o;
+                    }
+                    cum[r] = v;
+                    if (ln == 63) pf_wtot[r][wv] = v;
+                }
+                if (t == 0) { pf_e = -1; pf_count = 0; pf_floor_f = floor_f; }
+                __syncthreads();
+                const int64_t need = k < cls ? k : cls;
+                uint32_t carry = 0;      // everything above this thread's bin of round r
+#pragma unroll
+                for (int r = 0; r < PF_MAXR; ++r) {
+                    uint32_t before = carry;
+                    for (int w = 0; w < wv; ++w) before += pf_wtot[r][w];
+                    const int64_t here = (int64_t)before + cum[r], above = here - hv[r];
+                    if (r < rounds && need >= 1 && here >= need && above < need) { pf_e = top_f - (256 * r + t); pf_count = here; }      // one bin of one thread
+                    for (int w = 0; w < TK_THREADS / 64; ++w) carry += pf_wtot[r][w];
                 }
                 __syncthreads();
                 const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;

@@ -163,10 +163,12 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
 
 // ---- fine histogram: device side of the producers (score.hip, eig.hip) -------------------------------------------------
 // the floor is published in FINE bins: a maximum over the reporting units (replicas in separate cache lines)
-__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f)
+// ... together with the highest bin anybody reported (word 1 of the same line): the selection reads the table from there down
+__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f, int top_f)
 {
-    if (floor_f > 0)
-        __hip_atomic_fetch_max(&ws->pf_floor[blockIdx.x % PF_FLOOR_REP][0], (uint32_t)floor_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t *line = ws->pf_floor[blockIdx.x % PF_FLOOR_REP];
+    if (floor_f > 0) __hip_atomic_fetch_max(&line[0], (uint32_t)floor_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (top_f > 0) __hip_atomic_fetch_max(&line[1], (uint32_t)top_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Score kernels: the workgroup's tables (LDS, 16-bit counters, two per word; complete: call behind a workgroup barrier; 256
@@ -177,7 +179,7 @@ __device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f)
 static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const uint32_t *ftab, int mloc)
 {
     __shared__ uint32_t wtot[4];
-    __shared__ int s_floor;
+    __shared__ int s_floor, s_top;
     const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
     const uint32_t w0 = ctab[2 * t], w1 = ctab[2 * t + 1];
     const uint32_t hc[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
@@ -188,10 +190,11 @@ static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const u
         if (ln + off < 64) v += o;
     }
     if (ln == 0) wtot[wv] = v;
-    if (t == 0) s_floor = 0;
+    if (t == 0) { s_floor = 0; s_top = 0; }
     __syncthreads();
     for (int w = wv + 1; w < 4; ++w) v += wtot[w];
     uint32_t above = v - mine;
+    if (mine != 0 && above == 0) s_top = 4 * t + (hc[3] ? 3 : hc[2] ? 2 : hc[1] ? 1 : 0);      // the workgroup's highest non-empty bin: one thread
 #pragma unroll
     for (int c = 3; c >= 0; --c) {
         const uint32_t here = above + hc[c];
@@ -200,7 +203,7 @@ static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const u
     }
     __syncthreads();
     const int floor_c = s_floor;
-    if (t == 0) pf_publish_floor(ws, floor_c * PF_SUB);
+    if (t == 0) pf_publish_floor(ws, floor_c * PF_SUB, s_top * PF_SUB + PF_SUB - 1);
     if (4 * t + 3 < floor_c || mine == 0) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -220,26 +223,27 @@ static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const u
 // Every wave finds the third largest DISTINCT code among its lanes; the tile's floor is the smallest of the four, and every
 // member at or above it is reported by its own lane: at least three per wave, typically 15-25 per tile.  The tile fails the
 // selection's floor check only if EVERY one of its waves holds three members of the head (3e-10 per tile on 10^6 candidates in
-// random order).  One barrier; s_w3: four words of LDS.
+// random order).  One barrier; s_w3: eight words of LDS.
 static __device__ void pf_retire_keys(TopkWs *ws, int *s_w3, int fcode)
 {
     int m = fcode;      // wave maximum, three times, each below the previous one
-    int third = -1;
+    int third = -1, first = -1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int v = m;
         for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
         third = v;
+        if (r == 0) first = v;
         m = m >= v ? -1 : m;
     }
-    if ((threadIdx.x & 63) == 0) s_w3[threadIdx.x >> 6] = third;
+    if ((threadIdx.x & 63) == 0) { s_w3[threadIdx.x >> 6] = third; s_w3[4 + (threadIdx.x >> 6)] = first; }
     __syncthreads();
-    int fl = s_w3[0];
+    int fl = s_w3[0], top = s_w3[4];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) fl = s_w3[w] < fl ? s_w3[w] : fl;
+    for (int w = 1; w < 4; ++w) { fl = s_w3[w] < fl ? s_w3[w] : fl; top = s_w3[4 + w] > top ? s_w3[4 + w] : top; }
     // (a wave with fewer than three distinct codes reports everything it has: third = -1 -> the tile's floor is 0)
     fl = fl < 0 ? 0 : fl;
-    if (threadIdx.x == 0) pf_publish_floor(ws, fl);
+    if (threadIdx.x == 0) pf_publish_floor(ws, fl, top);
     if (fcode >= fl && fcode >= 0)
         __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(fcode)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

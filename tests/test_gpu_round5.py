@@ -138,10 +138,11 @@ def test_direct_selection_equals_the_radix_passes(count, sel):
             a, b, taken = _round_ab(sc, strat, sel, wl["vars_values"])
             _same_round(a, b)
             assert a["idx"].shape[0] == sel
+            print("count", count, "sel", sel, "strategy", strat, "direct", taken, "fine bin / floor / members", _round_ab.last, a["counters"])
             # (a head that is a large share of a short list can have its threshold in a fat bin or below the floor, a head of
             # exactly the sort buffers' size cannot have a superset that fits: the passes run)
             if count >= 10 ** 6 and sel <= 5000:
-                assert taken == 1, (strat, taken)
+                assert taken == 1, (strat, taken, _round_ab.last)
         assert sc.get_stat(_capi.STAT_SELECT_FALLBACKS) == 0
     finally:
         sc.close()
