@@ -71,14 +71,14 @@ constexpr int eig_pack_doubles(int kmax)
 
 template <int K, bool FUSE>
 __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol,
-                                         int *pf_code = nullptr)
+                                         int *pf_out = nullptr)
 {
     if (live) A.eig_out[out_idx] = lam;
     if constexpr (FUSE) {
         const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
         const uint64_t key = key_of(-lam);
         hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-        if (pf_code) *pf_code = viol ? pf_fcode(key, pf_base(true)) : -1;      // (r5) fine histogram of the class: reported when the tile retires
+        if (pf_out) *pf_out = viol ? pf_code(key, pf_base(true)) : -1;      // (r5) fine histogram of the class: reported when the tile retires
         c_viol += viol;
     }
 }
@@ -96,10 +96,10 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
 #if SDPCUT_LMIN
     // (r4) Householder + Laguerre, Jacobi for the lanes it hands back: no re-packing (the lanes Jacobi is left with are a few
     // per cent at structured vertices, none at generic points)
-    int pf_code = -1;
-    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_code);
+    int pf_c = -1;
+    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_c);
     if constexpr (FUSE) {
-        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 8 * par), pf_code);      // uniform; one barrier (every thread of the workgroup is here)
+        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 4 * par), pf_c);      // uniform; one barrier (every thread of the workgroup is here)
     }
     (void)s_state; (void)s_out; (void)cnt;
     return;
@@ -160,8 +160,13 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
     if (t >= hi) return;      // uniform
     int32_t s_nxt[K];
     int32_t orig_nxt;
+    // (r5) the four waves of a tile work on four DISTANT quarters of the class's list: wave w of tile T takes strip w * ntile + T
+    // (64 consecutive candidates, coalesced as before).  Real covers are enumerated index set by index set: neighbours share
+    // variables and scores, a run rich in head members would otherwise fill a whole tile (pf_retire_keys, topk_dev.h).
+    const int64_t ntile = hi - lo;
+    const int64_t wofs = (int64_t)(threadIdx.x >> 6) * ntile * 64 + (threadIdx.x & 63);
     {
-        const int64_t c = (t - lo) * 256 + threadIdx.x, cc = c < n ? c : n - 1;
+        const int64_t c = (t - lo) * 64 + wofs, cc = c < n ? c : n - 1;
         load_index_set<K>(s_nxt, A.set[K], n, cc);
         orig_nxt = A.orig[K][cc];
     }
@@ -170,9 +175,9 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
         const int32_t out_idx = orig_nxt;
-        const bool valid = (t - lo) * 256 + threadIdx.x < n;
+        const bool valid = (t - lo) * 64 + wofs < n;
         if (t + G < hi) {      // uniform
-            const int64_t c = (t + G - lo) * 256 + threadIdx.x, cc = c < n ? c : n - 1;
+            const int64_t c = (t + G - lo) * 64 + wofs, cc = c < n ? c : n - 1;
             load_index_set<K>(s_nxt, A.set[K], n, cc);
             orig_nxt = A.orig[K][cc];
         }
@@ -201,7 +206,7 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256 + 16];      // leading-digit histogram | (r5) the four waves' third largest and largest fine codes of the current / the next tile
+    __shared__ uint32_t tk_hist[256 + 8];      // leading-digit histogram | (r5) the four waves' third largest window codes of the current / the next tile
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];

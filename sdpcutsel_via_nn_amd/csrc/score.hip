@@ -473,8 +473,7 @@ struct MfmaLds {
     uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
     uint32_t tk_cnt[2];
     uint32_t s_strong;
-    uint32_t pf_tab[PF_FBINS / 2];   // (r5) the class members by fine window code, 16-bit counters, two per word (topk_dev.h)
-    uint32_t pf_ctab[PF_CBINS / 2];  // ... and by coarse code (8 fine bins): what a retiring workgroup scans
+    uint32_t pf_tab[PF_BINS / 2];    // (r5) the class members by window code, 16-bit counters, two per word (topk_dev.h)
 };
 
 // bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
@@ -567,9 +566,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
 #pragma unroll
-        for (int j = 0; j < PF_FBINS / 2 / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
-#pragma unroll
-        for (int j = 0; j < PF_CBINS / 2 / 256; ++j) S.pf_ctab[threadIdx.x + 256 * j] = 0;
+        for (int j = 0; j < PF_BINS / 2 / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
         __syncthreads();
     }
 
@@ -611,11 +608,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
                 const uint64_t key = key_of(-lam);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-                if (viol) {
-                    const int f = pf_fcode(key, pf_b);
-                    atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u);
-                    atomicAdd(&S.pf_ctab[f >> 4], (f & 8) ? 0x10000u : 1u);
-                }
+                if (viol) { const int f = pf_code(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
                 c_viol += viol;
             }
             tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
@@ -844,11 +837,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
                 const uint64_t key = key_of(FUSE == TK_MODE_FEAS ? -lam : obj);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), member);
-                if (member) {      // (LDS atomics without a return value: two ds_add per candidate)
-                    const int f = pf_fcode(key, pf_b);
-                    atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u);
-                    atomicAdd(&S.pf_ctab[f >> 4], (f & 8) ? 0x10000u : 1u);
-                }
+                if (member) { const int f = pf_code(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
@@ -887,7 +876,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-        if (A.pf_mloc > 0) pf_retire_table(A.tk, S.pf_ctab, pf_tab, A.pf_mloc);      // (behind the barrier above: the tables are complete)
+        if (A.pf_mloc > 0) pf_retire_table(A.tk, pf_tab, A.pf_mloc);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -1281,7 +1270,7 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
     A.tail_nhi = (tiles - lo * W + 3) / 4 * 4;
 }
 
-// How far down its table a workgroup of `per_wg` candidates reports (TopkWs::pf_fine, topk_dev.h): to its m-th largest member,
+// How far down its table a workgroup of `per_wg` candidates reports (TopkWs::pf_tab, topk_dev.h): to its m-th largest member,
 // m = 24 + eight times its expected share E of a head of k out of n_total candidates.  A workgroup with MORE members of the head
 // than that makes the selection fall back to its radix passes (the floor check).  For candidates in random order that never
 // happens (a Poisson variable of mean 2.6 reaching 45); real covers are enumerated index set by index set, neighbours share

@@ -159,7 +159,7 @@ static __device__ bool grid_barrier(TopkWs *ws, int b, uint32_t nblocks)
 // Mode COMBAUTO resolved to COMBALL (fewer strong candidates than asked for -- the score kernels
 // counted the STRONG keys): this launch runs its own pass 0 first, histogram in TopkWs::hist_alt.
 #define TK_CACHE 4096      // keys of a workgroup's chunk kept in LDS between the passes (32 KB)
-// (r5) DIRECT: the score / eigenvalue kernels also left the FINE histogram of the class (TopkWs::pf_fine, topk_dev.h).  Every
+// (r5) DIRECT: the score / eigenvalue kernels also left the FINE histogram of the class (TopkWs::pf_tab, topk_dev.h).  Every
 // workgroup resolves from it the window bin e* that holds the k-th largest key; if e* lies at or above the floor the producers
 // published and the members at or above e* fit the sort buffers -- the usual case: 5000 .. 5100 of 10^6 -- they are compacted in
 // ONE pass over the scores and handed to the sort exactly like an early stop of the digit passes: no histogram pass, no grid
@@ -193,8 +193,22 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         else return keys[i];
     };
     // ONFLY: the scores of the first batch are requested before digit 0 is resolved (they do not depend on it)
-    double pre_e[TK_UNROLL], pre_o[TK_UNROLL];
+    double pre_e[TK_UNROLL], pre_o[TK_UNROLL], pre_e2[TK_UNROLL], pre_o2[TK_UNROLL];
+    uint32_t pf_q[2 * (PF_BINS / 1024)][4];      // (r5) this thread's words of the fine table, both replicas, and of the floor
+    uint32_t pf_fl = 0;
     if constexpr (ONFLY) {
+        if (pf_k > 0) {      // uniform; coalesced 16-byte loads, independent of everything else the kernel reads
+            static_assert(PF_REP == 2 && PF_BINS % 1024 == 0, "two replicas of 1024-word blocks");
+#pragma unroll
+            for (int r = 0; r < PF_REP; ++r)
+#pragma unroll
+                for (int i = 0; i < PF_BINS / 1024; ++i) {
+                    const uint4 q = *(const uint4 *)&ws->pf_tab[r][1024 * i + 4 * threadIdx.x];
+                    pf_q[r * (PF_BINS / 1024) + i][0] = q.x; pf_q[r * (PF_BINS / 1024) + i][1] = q.y;
+                    pf_q[r * (PF_BINS / 1024) + i][2] = q.z; pf_q[r * (PF_BINS / 1024) + i][3] = q.w;
+                }
+            if ((threadIdx.x & 63) < PF_FLOOR_REP) pf_fl = ws->pf_floor[threadIdx.x & 63][0];
+        }
         if (lo < hi) {
 #pragma unroll
             for (int u = 0; u < TK_UNROLL; ++u) {
@@ -202,6 +216,15 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 const int64_t ic = i < hi ? i : hi - 1;
                 pre_e[u] = eig[ic];
                 pre_o[u] = obj[ic];
+            }
+            if (pf_k > 0 && use_cache) {      // uniform: the direct path reads its whole chunk (<= 4096 scores) without a second round trip
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = lo + (int64_t)(TK_UNROLL + u) * TK_THREADS + threadIdx.x;
+                    const int64_t ic = i < hi ? i : hi - 1;
+                    pre_e2[u] = eig[ic];
+                    pre_o2[u] = obj[ic];
+                }
             }
         }
         const bool both = mode == TK_MODE_COMBAUTO;
@@ -228,49 +251,42 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if (threadIdx.x == 0) { st1.prefix = 0; st1.need = k < cls ? k : cls; st1.stop = 0; }
         } else {
             if (pf_k > 0 && mode != TK_MODE_COMBALL) {
-                // ---- the fine table, read from the highest reported bin DOWN to the floor (typically 300-600 of the 8192 bins: two
-                // loads per thread instead of 32; plain loads: an earlier launch wrote them).  Thread t of round r owns bin
-                // top - (256 r + t): cumulative counts in thread order are suffix sums from the top.
-                constexpr int PF_MAXR = 8;
-                __shared__ uint32_t pf_wtot[PF_MAXR][TK_THREADS / 64];
+                // ---- the fine table (requested at the top of the kernel, in memory order: two replicas x 2048 words, consecutive
+                // bins in consecutive lines) goes through LDS into bin order -- the key cache is not in use yet --; thread t then owns
+                // bins 8 t .. 8 t + 7, suffix sums from the top.
+                __shared__ uint32_t pf_wtot[TK_THREADS / 64];
+                uint32_t *nat = (uint32_t *)cache;
                 const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
-                uint32_t fl = 0, tp = 0;
-                if (ln < PF_FLOOR_REP) { fl = ws->pf_floor[ln][0]; tp = ws->pf_floor[ln][1]; }
-                for (int off = 8; off > 0; off >>= 1) {
-                    const uint32_t a = (uint32_t)__shfl_xor((int)fl, off), b = (uint32_t)__shfl_xor((int)tp, off);
-                    fl = a > fl ? a : fl;
-                    tp = b > tp ? b : tp;
-                }
-                const int floor_f = __shfl((int)fl, 0), top_f = __shfl((int)tp, 0);      // uniform over the grid
-                // bins floor .. top, the highest 2048 of them at most (a k-th largest key further down: the passes run)
-                const int rounds = (top_f - floor_f + 256) / 256 < PF_MAXR ? (top_f - floor_f + 256) / 256 : PF_MAXR;
-                uint32_t hv[PF_MAXR], cum[PF_MAXR];
 #pragma unroll
-                for (int r = 0; r < PF_MAXR; ++r) {
-                    const int b = top_f - (256 * r + t);
-                    hv[r] = (r < rounds && b >= floor_f) ? ws->pf_fine[pf_slot(b)] : 0u;
-                }
+                for (int i = 0; i < PF_BINS / 1024; ++i)
 #pragma unroll
-                for (int r = 0; r < PF_MAXR; ++r) {
-                    uint32_t v = hv[r];      // inclusive prefix sum over the lanes
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t o = (uint32_t)__shfl_up((int)v, off);
-                        if (ln >= off) v += o;
+                    for (int j = 0; j < 4; ++j) {
+                        const int w = 1024 * i + 4 * t + j;      // word of a replica: bin (w % 32) * 64 + w / 32
+                        nat[(w & 31) * 64 + (w >> 5)] = pf_q[i][j] + pf_q[PF_BINS / 1024 + i][j];
                     }
-                    cum[r] = v;
-                    if (ln == 63) pf_wtot[r][wv] = v;
-                }
-                if (t == 0) { pf_e = -1; pf_count = 0; pf_floor_f = floor_f; }
+                uint32_t fl = pf_fl;
+                for (int off = 8; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)fl, off); fl = o > fl ? o : fl; }
+                if (t == 0) { pf_e = -1; pf_count = 0; pf_floor_f = (int)fl; }
                 __syncthreads();
-                const int64_t need = k < cls ? k : cls;
-                uint32_t carry = 0;      // everything above this thread's bin of round r
+                constexpr int PER = PF_BINS / TK_THREADS;      // 8
+                uint32_t hf[PER], mine8 = 0;
 #pragma unroll
-                for (int r = 0; r < PF_MAXR; ++r) {
-                    uint32_t before = carry;
-                    for (int w = 0; w < wv; ++w) before += pf_wtot[r][w];
-                    const int64_t here = (int64_t)before + cum[r], above = here - hv[r];
-                    if (r < rounds && need >= 1 && here >= need && above < need) { pf_e = top_f - (256 * r + t); pf_count = here; }      // one bin of one thread
-                    for (int w = 0; w < TK_THREADS / 64; ++w) carry += pf_wtot[r][w];
+                for (int j = 0; j < PER; ++j) { hf[j] = nat[PER * t + j]; mine8 += hf[j]; }
+                uint32_t v = mine8;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_down((int)v, off);
+                    if (ln + off < 64) v += o;
+                }
+                if (ln == 0) pf_wtot[wv] = v;
+                __syncthreads();
+                for (int w = wv + 1; w < TK_THREADS / 64; ++w) v += pf_wtot[w];
+                const int64_t need = k < cls ? k : cls;
+                int64_t above = (int64_t)(v - mine8);
+#pragma unroll
+                for (int j = PER - 1; j >= 0; --j) {
+                    const int64_t here = above + (int64_t)hf[j];
+                    if (need >= 1 && here >= need && above < need) { pf_e = PER * t + j; pf_count = here; }      // one bin of one thread
+                    above = here;
                 }
                 __syncthreads();
                 const int64_t maxk = k <= TK_LDSK ? TK_LDSK : TK_MAXK;
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 }
                 if (direct) {
                     const bool all_members = mode == TK_MODE_OPT;
-                    const uint64_t edge = pf_fedge(pf_e, pf_base(mode == TK_MODE_FEAS));
+                    const uint64_t edge = pf_edge(pf_e, pf_base(mode == TK_MODE_FEAS));
                     if (threadIdx.x == 0) {
                         st1.prefix = edge > 0ull || all_members ? edge : 1ull;      // (key 0 = not in the class)
                         st1.need = 1;
@@ -319,6 +335,13 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                         in[u] = lo + (int64_t)u * TK_THREADS + threadIdx.x < hi;
                         e[u] = pre_e[u];
                         o[u] = pre_o[u];
+                    }
+                } else if (use_cache && r0 == lo + (int64_t)TK_UNROLL * TK_THREADS) {      // uniform: the second batch, requested there as well
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        in[u] = r0 + (int64_t)u * TK_THREADS + threadIdx.x < hi;
+                        e[u] = pre_e2[u];
+                        o[u] = pre_o2[u];
                     }
                 } else {
 #pragma unroll
@@ -947,7 +970,7 @@ int topk_alt_ws(sdpcut_ctx *h, uint64_t **ptr, int *words)
     *ptr = (uint64_t *)h->d_topk_ws_alt;
     // (r5) lists too short for the fine histogram (it sits at the end of the struct) zero only what lies in front of it: the epilogue
     // of a round with a handful of cuts is a handful of workgroups, and every word is a store on its critical path
-    static_assert(offsetof(TopkWs, pf_floor) % 8 == 0 && offsetof(TopkWs, pf_fine) > offsetof(TopkWs, pf_floor), "fine histogram last");
+    static_assert(offsetof(TopkWs, pf_floor) % 8 == 0 && offsetof(TopkWs, pf_tab) > offsetof(TopkWs, pf_floor), "fine histogram last");
     *words = (int)((h->N >= SDPCUT_PF_MIN_N ? sizeof(TopkWs) : offsetof(TopkWs, pf_floor)) / 8);
     return 0;
 }

@@ -38,38 +38,37 @@
 // leading-digit histogram the score kernels count (hist_score) only saves the selection its first pass: tk_refine_kernel still
 // ran one or two histogram passes behind grid barriers over all 10^6 keys to find ~5000 of them (25 us of a 387 us round,
 // 75 % of what a feasibility round spends outside its 28 us eigenvalue kernel).  Now the kernels that produce the scores also
-// count the members by the top NINETEEN bits of the key (sign, exponent, seven mantissa bits: 0.8 % resolution) inside a window
-// of 8192 codes and report only the TOP of what they saw: a score workgroup keeps a table in LDS and reports, when it retires, the
-// bins down to the coarse bin (8 fine bins) that holds its m-th largest member, m a few times its expected share of the head
-// (pf_mloc); a tile of the eigenvalue kernel reports the members down to the smallest of its four waves' third largest codes.
-// Each also publishes the lowest bin it reported (pf_floor, a maximum over all of them).  Every fine bin at or above the floor
-// is then EXACT.  The selection finds the fine bin e* of the k-th largest key in the global
-// table; if e* lies at or above the floor -- no workgroup held more than m members of the head: always, unless the list is
-// sorted by score -- and the members at or above e* fit the sort buffers, it compacts them in ONE pass over the scores without
-// reading a key twice, without a histogram pass, without a grid barrier (tk_refine_kernel, `direct`).  Otherwise (a workgroup
-// rich in head members; a fat bin: masses of equal keys at a structured LP vertex; the every-entry-visited regime, whose keys
-// are not the ones counted) the radix passes run as before: same result either way.
-// What it costs the producers: one LDS atomic per candidate, ~100 instructions per thread when a workgroup retires (1 % of the
-// score kernel), and ~20-30 no-return device atomics per workgroup spread over a few hundred addresses in different cache
-// lines (profiles/r05_ubench_atomics.txt: device atomics serialise per ADDRESS at 11 ns and per 128-B line at 1.6 ns; the first
-// version of this -- every member reported at 16-bit resolution into 4 KB -- queued 3e5 atomics on ~25 hot words of one or two
-// lines and cost the eigenvalue kernel 200 us).
-// Window: coarse codes (top 16 bits) [base, base + 1023] x 8 sub-bins, clamped on both sides (the lowest bin also holds
-// everything below, the highest everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
-#define PF_CBINS 1024                   // coarse bins (top 16 key bits)
-#define PF_SUB 8                        // fine bins per coarse bin (3 more bits)
-#define PF_FBINS (PF_CBINS * PF_SUB)    // 8192
+// count the members by the top SEVENTEEN bits of the key (sign, exponent, five mantissa bits: 3 % resolution) inside a window
+// of 2048 codes and report only the TOP of what they saw: a score workgroup keeps a table in LDS (one LDS atomic per
+// candidate) and reports, when it retires, the bins down to the one that holds its m-th largest member, m a few times its
+// expected share of the head (pf_mloc); a tile of the eigenvalue kernel reports the members down to the smallest of its four
+// waves' third largest codes.  Each also publishes the lowest bin it reported (pf_floor, a maximum over all of them).  Every
+// bin at or above the floor is then EXACT.  The selection finds the bin e* of the k-th largest key in the global table; if e*
+// lies at or above the floor -- no reporting unit held more members of the head than it reported: always, unless the list is
+// sorted by score -- and the members at or above e* fit the sort buffers, it compacts them in ONE pass over the scores: no
+// histogram pass, no grid barrier, and everything it reads is requested by its very first instructions (tk_refine_kernel,
+// `direct`).  Otherwise (a unit rich in head members; a fat bin: masses of equal keys at a structured LP vertex; the
+// every-entry-visited regime, whose keys are not the ones counted) the radix passes run as before: same result either way.
+// What it costs the producers: one LDS atomic per candidate, ~170 instructions of ONE wave when a workgroup retires, and ~15
+// no-return device atomics per workgroup.  Device atomics serialise per ADDRESS at 11 ns and per 128-B line at 1.6-2 ns
+// (profiles/r05_ubench_atomics.txt; the first version -- every member reported at 16-bit resolution into 4 KB -- queued 3e5
+// atomics on ~25 hot words of two lines and cost the eigenvalue kernel 200 us): consecutive bins therefore sit in consecutive
+// LINES (a hot run of bins = as many lines), and there are two replicas.
+// Window: codes (top 17 bits) [base, base + 2047], clamped on both sides (the lowest bin also holds everything below, the
+// highest everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
+#define PF_BINS 2048                    // 17-bit codes
+#define PF_REP 2                        // replicas of the global table (by workgroup)
 #define PF_FLOOR_REP 16                 // replicas of the floor word, one 128-B line each
-__device__ __forceinline__ int pf_base(bool feas) { return (feas ? 0xC070 : 0xC170) - (PF_CBINS - 1); }
-__device__ __forceinline__ int pf_fcode(uint64_t key, int base)
+__device__ __forceinline__ int pf_base(bool feas) { return 2 * ((feas ? 0xC070 : 0xC170) - (PF_BINS / 2 - 1)); }
+__device__ __forceinline__ int pf_code(uint64_t key, int base)
 {
-    const int c = (int)(uint32_t)(key >> 45) - base * PF_SUB;
-    return c < 0 ? 0 : (c > PF_FBINS - 1 ? PF_FBINS - 1 : c);
+    const int c = (int)(uint32_t)(key >> 47) - base;
+    return c < 0 ? 0 : (c > PF_BINS - 1 ? PF_BINS - 1 : c);
 }
-// lowest key of fine bin f (0: everything)
-__device__ __forceinline__ uint64_t pf_fedge(int f, int base) { return f <= 0 ? 0ull : (uint64_t)(uint32_t)(base * PF_SUB + f) << 45; }
-// word of fine bin f in the global table: consecutive bins in consecutive 128-B lines (a hot run of bins = as many lines)
-__device__ __forceinline__ int pf_slot(int f) { return (f & 255) * 32 + (f >> 8); }
+// lowest key of bin f (0: everything)
+__device__ __forceinline__ uint64_t pf_edge(int f, int base) { return f <= 0 ? 0ull : (uint64_t)(uint32_t)(base + f) << 47; }
+// word of bin f inside a replica of the global table: consecutive bins in consecutive 128-B lines
+__device__ __forceinline__ int pf_slot(int f) { return (f & 63) * 32 + (f >> 6); }
 
 // 4: combined strategy when the scan visits every entry -- the key is the new score of
 // cut_select_qp.py:606-623, ties between equal new scores go by obj_improve, then index
@@ -111,8 +110,8 @@ struct TopkWs {
                                           // apiece: 58 us for the eigenvalue kernel's 3907 workgroups -- longer than the kernel runs)
     // (r5) the FINE histogram the score / eigenvalue kernels leave for the selection (see above); LAST in the struct: lists too
     // short for it zero only what lies in front (offsetof(TopkWs, pf_floor))
-    uint32_t pf_floor[PF_FLOOR_REP][32];  // max over workgroups of the lowest FINE bin they reported (replicas in separate lines)
-    uint32_t pf_fine[PF_FBINS];           // class members by fine window code, word pf_slot(f)
+    uint32_t pf_floor[PF_FLOOR_REP][32];  // max over the reporting units of the lowest bin they reported (replicas in separate lines)
+    uint32_t pf_tab[PF_REP][PF_BINS];     // class members by window code, word pf_slot(f) of replica blockIdx % PF_REP
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
@@ -162,90 +161,79 @@ __device__ __forceinline__ void hist_add_few(uint32_t *hist, uint32_t bin, bool 
 }
 
 // ---- fine histogram: device side of the producers (score.hip, eig.hip) -------------------------------------------------
-// the floor is published in FINE bins: a maximum over the reporting units (replicas in separate cache lines)
-// ... together with the highest bin anybody reported (word 1 of the same line): the selection reads the table from there down
-__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f, int top_f)
+__device__ __forceinline__ void pf_publish_floor(TopkWs *ws, int floor_f)
 {
-    uint32_t *line = ws->pf_floor[blockIdx.x % PF_FLOOR_REP];
-    if (floor_f > 0) __hip_atomic_fetch_max(&line[0], (uint32_t)floor_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (top_f > 0) __hip_atomic_fetch_max(&line[1], (uint32_t)top_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (floor_f > 0)
+        __hip_atomic_fetch_max(&ws->pf_floor[blockIdx.x % PF_FLOOR_REP][0], (uint32_t)floor_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pf_report(TopkWs *ws, int f, uint32_t count)
+{
+    __hip_atomic_fetch_add(&ws->pf_tab[blockIdx.x % PF_REP][pf_slot(f)], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Score kernels: the workgroup's tables (LDS, 16-bit counters, two per word; complete: call behind a workgroup barrier; 256
-// threads): `ctab` PF_CBINS coarse counters, `ftab` PF_FBINS fine ones.  Thread t owns coarse bins 4 t .. 4 t + 3 (fine bins
-// 32 t .. 32 t + 31).  Reports the fine bins of every coarse bin down to the one that holds the workgroup's mloc-th largest
-// member (fewer members than that: everything).  ~40 instructions and three barriers per thread; the few threads at the top
-// of the table also read their fine counters and issue the atomics.
-static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *ctab, const uint32_t *ftab, int mloc)
+// Score kernels: the workgroup's table `tab` (LDS, PF_BINS counters of 16 bits, two per word; complete: call behind a workgroup
+// barrier).  ONE wave does it (the others are done): lane l owns bins 32 l .. 32 l + 31.  Reports every bin down to the one that
+// holds the workgroup's mloc-th largest member (fewer members than that: everything) and publishes that bin as its floor.
+static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc)
 {
-    __shared__ uint32_t wtot[4];
-    __shared__ int s_floor, s_top;
-    const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
-    const uint32_t w0 = ctab[2 * t], w1 = ctab[2 * t + 1];
-    const uint32_t hc[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
-    const uint32_t mine = hc[0] + hc[1] + hc[2] + hc[3];
-    uint32_t v = mine;      // suffix sums: thread t's bins lie above thread t - 1's
+    if (threadIdx.x >= 64) return;
+    const int l = threadIdx.x;
+    uint32_t h[32], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t w = tab[16 * l + j];
+        h[2 * j] = w & 0xffffu;
+        h[2 * j + 1] = w >> 16;
+        mine += h[2 * j] + h[2 * j + 1];
+    }
+    uint32_t v = mine;      // suffix sums: lane l's bins lie above lane l - 1's
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_down((int)v, off);
-        if (ln + off < 64) v += o;
+        if (l + off < 64) v += o;
     }
-    if (ln == 0) wtot[wv] = v;
-    if (t == 0) { s_floor = 0; s_top = 0; }
-    __syncthreads();
-    for (int w = wv + 1; w < 4; ++w) v += wtot[w];
     uint32_t above = v - mine;
-    if (mine != 0 && above == 0) s_top = 4 * t + (hc[3] ? 3 : hc[2] ? 2 : hc[1] ? 1 : 0);      // the workgroup's highest non-empty bin: one thread
+    int floor_f = -1;
 #pragma unroll
-    for (int c = 3; c >= 0; --c) {
-        const uint32_t here = above + hc[c];
-        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) s_floor = 4 * t + c;      // one bin of one thread
+    for (int c = 31; c >= 0; --c) {
+        const uint32_t here = above + h[c];
+        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) floor_f = 32 * l + c;      // one bin of one lane
         above = here;
     }
-    __syncthreads();
-    const int floor_c = s_floor;
-    if (t == 0) pf_publish_floor(ws, floor_c * PF_SUB, s_top * PF_SUB + PF_SUB - 1);
-    if (4 * t + 3 < floor_c || mine == 0) return;
+    const unsigned long long mf = __ballot(floor_f >= 0);
+    floor_f = mf ? __shfl(floor_f, __ffsll((long long)mf) - 1) : 0;      // (a lane index from the ballot: wave-uniform)
+    if (l == 0) pf_publish_floor(ws, floor_f);
+    if (32 * l + 31 < floor_f || mine == 0) return;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (4 * t + c < floor_c || hc[c] == 0) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t w = ftab[16 * t + 4 * c + j];
-            const uint32_t lo = w & 0xffffu, hi = w >> 16;
-            const int f = 32 * t + 8 * c + 2 * j;
-            if (lo) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (hi) __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(f + 1)], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    for (int c = 0; c < 32; ++c)
+        if (32 * l + c >= floor_f && h[c]) pf_report(ws, 32 * l + c, h[c]);
 }
 
-// Eigenvalue kernel (a thread = a candidate of the tile, its fine code in a register: -1 = not in the class): no table at all.
+// Eigenvalue kernel (a thread = a candidate of the tile, its code in a register: -1 = not in the class): no table at all.
 // Every wave finds the third largest DISTINCT code among its lanes; the tile's floor is the smallest of the four, and every
 // member at or above it is reported by its own lane: at least three per wave, typically 15-25 per tile.  The tile fails the
-// selection's floor check only if EVERY one of its waves holds three members of the head (3e-10 per tile on 10^6 candidates in
-// random order).  One barrier; s_w3: eight words of LDS.
-static __device__ void pf_retire_keys(TopkWs *ws, int *s_w3, int fcode)
+// selection's floor check only if EVERY one of its waves holds three members of the head; the four waves of a tile work on
+// four distant quarters of the list (eig_class), so that a run of consecutive candidates rich in head members -- real covers
+// are enumerated index set by index set -- fills ONE of them.  One barrier; s_w3: four words of LDS.
+static __device__ void pf_retire_keys(TopkWs *ws, int *s_w3, int code)
 {
-    int m = fcode;      // wave maximum, three times, each below the previous one
-    int third = -1, first = -1;
+    int m = code;      // wave maximum, three times, each below the previous one
+    int third = -1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int v = m;
         for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
         third = v;
-        if (r == 0) first = v;
         m = m >= v ? -1 : m;
     }
-    if ((threadIdx.x & 63) == 0) { s_w3[threadIdx.x >> 6] = third; s_w3[4 + (threadIdx.x >> 6)] = first; }
+    if ((threadIdx.x & 63) == 0) s_w3[threadIdx.x >> 6] = third;
     __syncthreads();
-    int fl = s_w3[0], top = s_w3[4];
+    int fl = s_w3[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) { fl = s_w3[w] < fl ? s_w3[w] : fl; top = s_w3[4 + w] > top ? s_w3[4 + w] : top; }
+    for (int w = 1; w < 4; ++w) fl = s_w3[w] < fl ? s_w3[w] : fl;
     // (a wave with fewer than three distinct codes reports everything it has: third = -1 -> the tile's floor is 0)
     fl = fl < 0 ? 0 : fl;
-    if (threadIdx.x == 0) pf_publish_floor(ws, fl, top);
-    if (fcode >= fl && fcode >= 0)
-        __hip_atomic_fetch_add(&ws->pf_fine[pf_slot(fcode)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) pf_publish_floor(ws, fl);
+    if (code >= fl && code >= 0) pf_report(ws, code, 1u);
 }
 
 // Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].
