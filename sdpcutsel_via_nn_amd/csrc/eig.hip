@@ -33,7 +33,7 @@ struct EigArgs {
     int64_t L;
     double *eig_out;
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
-    int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): every tile reports its largest members (pf_retire_keys); 0: off
+    int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): a workgroup reports its table down to its pf_mloc-th largest member; 0: off
 };
 
 // ---- re-packing the lanes that have not converged ------------------------------------------------------------
@@ -71,14 +71,17 @@ constexpr int eig_pack_doubles(int kmax)
 
 template <int K, bool FUSE>
 __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol,
-                                         int *pf_out = nullptr)
+                                         int *pf_out = nullptr)      // (pf_out: unused)
 {
     if (live) A.eig_out[out_idx] = lam;
     if constexpr (FUSE) {
         const bool viol = live && lam < SDPCUT_NEG_EIGVAL;
         const uint64_t key = key_of(-lam);
         hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-        if (pf_out) *pf_out = viol ? pf_code(key, pf_base(true)) : -1;      // (r5) fine histogram of the class: reported when the tile retires
+        if (viol && A.pf_mloc > 0) {      // (r5) fine histogram of the class: the workgroup's table sits behind the leading-digit histogram
+            const int f = pf_code(key, pf_base(true));
+            atomicAdd(&tk_hist[256 + (f >> 1)], (f & 1) ? 0x10000u : 1u);
+        }
         c_viol += viol;
     }
 }
@@ -96,11 +99,7 @@ __device__ __forceinline__ void eig_tile(const EigArgs &A, const int32_t (&s)[K]
 #if SDPCUT_LMIN
     // (r4) Householder + Laguerre, Jacobi for the lanes it hands back: no re-packing (the lanes Jacobi is left with are a few
     // per cent at structured vertices, none at generic points)
-    int pf_c = -1;
-    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol, &pf_c);
-    if constexpr (FUSE) {
-        if (A.pf_mloc > 0) pf_retire_keys(A.tk, (int *)(tk_hist + 256 + 4 * par), pf_c);      // uniform; one barrier (every thread of the workgroup is here)
-    }
+    eig_emit<K, FUSE>(A, candidate_eigmin<K>(cd, s, A.vars, A.nv, A.L), out_idx, valid, tk_hist, c_viol);
     (void)s_state; (void)s_out; (void)cnt;
     return;
 #endif
@@ -206,14 +205,15 @@ template <int KMAX> struct EigOcc { static constexpr int W = KMAX <= 3 ? SDPCUT_
 template <int KMAX, bool FUSE>
 __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs A)
 {
-    __shared__ uint32_t tk_hist[256 + 8];      // leading-digit histogram | (r5) the four waves' third largest window codes of the current / the next tile
+    __shared__ uint32_t tk_hist[256 + (FUSE ? PF_BINS / 2 : 0)];      // leading-digit histogram | (r5) the workgroup's table of window codes, 16-bit counters (topk_dev.h)
     __shared__ uint32_t tk_cnt;
     __shared__ double s_state[eig_pack_doubles(KMAX)];
     __shared__ int32_t s_out[256];
     __shared__ uint32_t s_packed[2];      // packed-lane counters of the current / the next tile
     if (threadIdx.x < 2) s_packed[threadIdx.x] = 0;
     if constexpr (FUSE) {
-        tk_hist[threadIdx.x] = 0;
+#pragma unroll
+        for (int j = 0; j < 1 + PF_BINS / 2 / 256; ++j) tk_hist[threadIdx.x + 256 * j] = 0;
         if (threadIdx.x == 0) tk_cnt = 0;
     }
     __syncthreads();
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+        if (A.pf_mloc > 0) pf_retire_table(A.tk, tk_hist + 256, A.pf_mloc);      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -247,11 +248,22 @@ __global__ __launch_bounds__(256, EigOcc<KMAX>::W) void eig_only_kernel(EigArgs 
 #endif
 
 template <int KMAX, bool FUSE>
-static void eig_launch(sdpcut_ctx *h, const EigArgs &A, hipEvent_t ev_start, hipEvent_t ev_stop)
+static void eig_launch(sdpcut_ctx *h, EigArgs &A, hipEvent_t ev_start, hipEvent_t ev_stop, int64_t pf_k)
 {
     const int64_t ntiles = A.tile_end[2];
     int64_t cap = (int64_t)h->n_cu * EigOcc<KMAX>::W * SDPCUT_EIG_BLOCKS_PER_SLOT;
+    // (r5) with the fine histogram: ONE workgroup per resident slot, two or three tiles each -- a workgroup reports the top of its
+    // table once, when it retires, and the table is only worth its scan over a few hundred members
+    if (FUSE && pf_k > 0) cap = (int64_t)h->n_cu * EigOcc<KMAX>::W;
     const int grid = (int)(ntiles < cap ? ntiles : cap);
+    A.pf_mloc = 0;
+#if SDPCUT_LMIN
+    if (FUSE && pf_k > 0 && h->N > 0) {      // as pf_mloc_for (score.hip): 24 + eight times the workgroup's expected share of the head
+        const int64_t per_wg = (ntiles + grid - 1) / grid * 256;
+        const double m = 24.0 + 8.0 * (double)pf_k * (double)per_wg / (double)h->N;
+        A.pf_mloc = per_wg >= 60000 ? 0 : (m > 60000.0 ? 60000 : (int)(m + 0.999));
+    }
+#endif
     if (ev_start || ev_stop)
         hipExtLaunchKernelGGL((eig_only_kernel<KMAX, FUSE>), dim3(grid), dim3(256), 0, h->stream, ev_start, ev_stop, 0, A);
     else
@@ -275,15 +287,11 @@ int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_
     A.set[0] = A.set[1] = nullptr; A.orig[0] = A.orig[1] = nullptr; A.n[0] = A.n[1] = 0; A.tile_end[0] = A.tile_end[1] = acc;
     if (kmax == 0) return 0;
     A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk;
-    // fine histogram of the class (topk_dev.h: pf_retire_keys): the Householder + Laguerre path only (one value per lane and tile)
-    A.pf_mloc = 0;
-#if SDPCUT_LMIN
-    if (tk && pf_k > 0) A.pf_mloc = 3;
-#endif
+    A.pf_mloc = 0;      // (set with the grid: eig_launch)
 #define EIG_LAUNCH(KM)                                                   \
     do {                                                                 \
-        if (tk) eig_launch<KM, true>(h, A, ev_start, ev_stop);           \
-        else eig_launch<KM, false>(h, A, ev_start, ev_stop);             \
+        if (tk) eig_launch<KM, true>(h, A, ev_start, ev_stop, pf_k);     \
+        else eig_launch<KM, false>(h, A, ev_start, ev_stop, 0);          \
     } while (0)
     switch (kmax) {
     case 2: EIG_LAUNCH(2); break;

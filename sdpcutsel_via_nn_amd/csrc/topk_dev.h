@@ -41,9 +41,9 @@
 // count the members by the top SEVENTEEN bits of the key (sign, exponent, five mantissa bits: 3 % resolution) inside a window
 // of 2048 codes and report only the TOP of what they saw: a score workgroup keeps a table in LDS (one LDS atomic per
 // candidate) and reports, when it retires, the bins down to the one that holds its m-th largest member, m a few times its
-// expected share of the head (pf_mloc); a tile of the eigenvalue kernel reports the members down to the smallest of its four
-// waves' third largest codes.  Each also publishes the lowest bin it reported (pf_floor, a maximum over all of them).  Every
-// bin at or above the floor is then EXACT.  The selection finds the bin e* of the k-th largest key in the global table; if e*
+// expected share of the head (pf_mloc); so does a workgroup of the eigenvalue kernel (two or three tiles each when it counts).
+// Each also publishes the lowest bin it reported (pf_floor, a maximum over all of them).  Every bin at or above the floor is
+// then EXACT.  The selection finds the bin e* of the k-th largest key in the global table; if e*
 // lies at or above the floor -- no reporting unit held more members of the head than it reported: always, unless the list is
 // sorted by score -- and the members at or above e* fit the sort buffers, it compacts them in ONE pass over the scores: no
 // histogram pass, no grid barrier, and everything it reads is requested by its very first instructions (tk_refine_kernel,
@@ -171,69 +171,46 @@ __device__ __forceinline__ void pf_report(TopkWs *ws, int f, uint32_t count)
     __hip_atomic_fetch_add(&ws->pf_tab[blockIdx.x % PF_REP][pf_slot(f)], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Score kernels: the workgroup's table `tab` (LDS, PF_BINS counters of 16 bits, two per word; complete: call behind a workgroup
-// barrier).  ONE wave does it (the others are done): lane l owns bins 32 l .. 32 l + 31.  Reports every bin down to the one that
-// holds the workgroup's mloc-th largest member (fewer members than that: everything) and publishes that bin as its floor.
+// The producers' side: a workgroup's table `tab` (LDS, PF_BINS counters of 16 bits, two per word; complete: call behind a
+// workgroup barrier; 256 threads).  Thread t owns bins 8 t .. 8 t + 7.  Reports every bin down to the one that holds the
+// workgroup's mloc-th largest member (fewer members than that: everything) and publishes that bin as its floor.  All four waves
+// work (a retiring workgroup holds its slot until its last wave is done: 40 instructions each beat 170 of one wave); two barriers.
 static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc)
 {
-    if (threadIdx.x >= 64) return;
-    const int l = threadIdx.x;
-    uint32_t h[32], mine = 0;
+    __shared__ uint32_t wtot[4];
+    __shared__ int s_floor;
+    const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
+    uint32_t h[8], mine = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t w = tab[16 * l + j];
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = tab[4 * t + j];
         h[2 * j] = w & 0xffffu;
         h[2 * j + 1] = w >> 16;
         mine += h[2 * j] + h[2 * j + 1];
     }
-    uint32_t v = mine;      // suffix sums: lane l's bins lie above lane l - 1's
+    uint32_t v = mine;      // suffix sums: thread t's bins lie above thread t - 1's
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_down((int)v, off);
-        if (l + off < 64) v += o;
+        if (ln + off < 64) v += o;
     }
+    if (ln == 0) wtot[wv] = v;
+    if (t == 0) s_floor = 0;
+    __syncthreads();
+    for (int w = wv + 1; w < 4; ++w) v += wtot[w];
     uint32_t above = v - mine;
-    int floor_f = -1;
 #pragma unroll
-    for (int c = 31; c >= 0; --c) {
+    for (int c = 7; c >= 0; --c) {
         const uint32_t here = above + h[c];
-        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) floor_f = 32 * l + c;      // one bin of one lane
+        if (here >= (uint32_t)mloc && above < (uint32_t)mloc) s_floor = 8 * t + c;      // one bin of one thread
         above = here;
     }
-    const unsigned long long mf = __ballot(floor_f >= 0);
-    floor_f = mf ? __shfl(floor_f, __ffsll((long long)mf) - 1) : 0;      // (a lane index from the ballot: wave-uniform)
-    if (l == 0) pf_publish_floor(ws, floor_f);
-    if (32 * l + 31 < floor_f || mine == 0) return;
-#pragma unroll
-    for (int c = 0; c < 32; ++c)
-        if (32 * l + c >= floor_f && h[c]) pf_report(ws, 32 * l + c, h[c]);
-}
-
-// Eigenvalue kernel (a thread = a candidate of the tile, its code in a register: -1 = not in the class): no table at all.
-// Every wave finds the third largest DISTINCT code among its lanes; the tile's floor is the smallest of the four, and every
-// member at or above it is reported by its own lane: at least three per wave, typically 15-25 per tile.  The tile fails the
-// selection's floor check only if EVERY one of its waves holds three members of the head; the four waves of a tile work on
-// four distant quarters of the list (eig_class), so that a run of consecutive candidates rich in head members -- real covers
-// are enumerated index set by index set -- fills ONE of them.  One barrier; s_w3: four words of LDS.
-static __device__ void pf_retire_keys(TopkWs *ws, int *s_w3, int code)
-{
-    int m = code;      // wave maximum, three times, each below the previous one
-    int third = -1;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        int v = m;
-        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
-        third = v;
-        m = m >= v ? -1 : m;
-    }
-    if ((threadIdx.x & 63) == 0) s_w3[threadIdx.x >> 6] = third;
     __syncthreads();
-    int fl = s_w3[0];
+    const int floor_f = s_floor;
+    if (t == 0) pf_publish_floor(ws, floor_f);
+    if (8 * t + 7 < floor_f || mine == 0) return;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) fl = s_w3[w] < fl ? s_w3[w] : fl;
-    // (a wave with fewer than three distinct codes reports everything it has: third = -1 -> the tile's floor is 0)
-    fl = fl < 0 ? 0 : fl;
-    if (threadIdx.x == 0) pf_publish_floor(ws, fl);
-    if (code >= fl && code >= 0) pf_report(ws, code, 1u);
+    for (int c = 0; c < 8; ++c)
+        if (8 * t + c >= floor_f && h[c]) pf_report(ws, 8 * t + c, h[c]);
 }
 
 // Executed by the LAST block of pass p: resolve digit 7-p and publish state[p+1].
