@@ -79,7 +79,7 @@ __device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t o
         const uint64_t key = key_of(-lam);
         hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
         if (viol && A.pf_mloc > 0) {      // (r5) fine histogram of the class: the workgroup's table sits behind the leading-digit histogram
-            const int f = pf_code(key, pf_base(true));
+            const int f = pf_code(key, true);
             atomicAdd(&tk_hist[256 + (f >> 1)], (f & 1) ? 0x10000u : 1u);
         }
         c_viol += viol;

@@ -513,7 +513,12 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     //    not pay: a single-tile pass of a lone wave takes as long as a two-tile pass, profiles/r03_k3_kernel_time_vs_list_length.txt.)
     // The last strip of a list may hold fewer candidates: it runs the passes its column tiles need, the last one over a single
     // tile if their number is odd (mlp_pass<1>: the same arithmetic per candidate, bit-equal scores).
-    const int64_t gw = (int64_t)bid * 4 + wave;
+    // (r5) ... no longer: wave w of workgroup b is wave w * nblk + b of the launch -- the four waves of a workgroup work on four DISTANT
+    // quarters of the list (the resident workgroups still move through each quarter together: four streams instead of one).  Real
+    // covers are enumerated index set by index set, neighbours share variables and scores: a run of consecutive candidates rich in
+    // members of the head would otherwise fill a whole workgroup, which then reports fewer of them than it holds and sends the
+    // selection through its radix passes (pf_retire_table, topk_dev.h).  Scores do not depend on who computes them.
+    const int64_t gw = (int64_t)wave * nblk + bid;
     const int64_t wstride = (int64_t)nblk * 4 * A.strip;      // candidates between two strips of one wave
     const int64_t c_first = gw * A.strip;
     // ... and the LAST round of a list of a few rounds, when it is nearly full (r4): 10^6 candidates are 7.63 strips per resident
@@ -561,7 +566,6 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     auto &tk_cnt = S.tk_cnt;
     uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
     auto &pf_tab = S.pf_tab;
-    const int pf_b = pf_base(FUSE == TK_MODE_FEAS);
     if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
@@ -608,7 +612,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
                 const uint64_t key = key_of(-lam);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-                if (viol) { const int f = pf_code(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
+                if (viol) { const int f = pf_code(key, true); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
                 c_viol += viol;
             }
             tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
@@ -837,7 +841,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
                 const uint64_t key = key_of(FUSE == TK_MODE_FEAS ? -lam : obj);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), member);
-                if (member) { const int f = pf_code(key, pf_b); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
+                if (member) { const int f = pf_code(key, FUSE == TK_MODE_FEAS); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
                 }
                 if (direct) {
                     const bool all_members = mode == TK_MODE_OPT;
-                    const uint64_t edge = pf_edge(pf_e, pf_base(mode == TK_MODE_FEAS));
+                    const uint64_t edge = pf_edge(pf_e, mode == TK_MODE_FEAS);
                     if (threadIdx.x == 0) {
                         st1.prefix = edge > 0ull || all_members ? edge : 1ull;      // (key 0 = not in the class)
                         st1.need = 1;

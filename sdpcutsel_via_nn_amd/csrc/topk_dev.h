@@ -54,19 +54,31 @@
 // (profiles/r05_ubench_atomics.txt; the first version -- every member reported at 16-bit resolution into 4 KB -- queued 3e5
 // atomics on ~25 hot words of two lines and cost the eigenvalue kernel 200 us): consecutive bins therefore sit in consecutive
 // LINES (a hot run of bins = as many lines), and there are two replicas.
-// Window: codes (top 17 bits) [base, base + 2047], clamped on both sides (the lowest bin also holds everything below, the
-// highest everything above): -lambda_min in (1e-15, 8] needs 54 binades, obj_improve gets 2^-40 .. 2^24.
+// Window of 2048 bins over the 17-bit codes, clamped on both sides (a bin at an end of a range also holds everything beyond it):
+//   feasibility keys (-lambda_min in (1e-15, 8]):  one range, 2^-56 .. 2^8 (64 binades of 32 codes);
+//   obj_improve keys:  1024 bins for -2^16 .. -2^-16 and 1024 for 2^-16 .. 2^16 -- on dense instances the optimality ranking's
+//   5000-th score is NEGATIVE from the fourth round on (spar090-075-1, spar125-075-1 dim 3: fewer than 300 positive scores).
 #define PF_BINS 2048                    // 17-bit codes
 #define PF_REP 2                        // replicas of the global table (by workgroup)
 #define PF_FLOOR_REP 16                 // replicas of the floor word, one 128-B line each
-__device__ __forceinline__ int pf_base(bool feas) { return 2 * ((feas ? 0xC070 : 0xC170) - (PF_BINS / 2 - 1)); }
-__device__ __forceinline__ int pf_code(uint64_t key, int base)
+#define PF_FEAS_BASE (0x10000 + ((1023 + 8) << 5) - PF_BINS)      // code of 2^8 minus the window
+#define PF_POS_BASE (0x10000 + ((1023 - 16) << 5))                 // code of 2^-16
+#define PF_NEG_BASE (0xFFFF - ((1023 + 16) << 5) + 1)              // code of the smallest key above -2^16
+__device__ __forceinline__ int pf_clamp(int c, int n) { return c < 0 ? 0 : (c > n - 1 ? n - 1 : c); }
+__device__ __forceinline__ int pf_code(uint64_t key, bool feas)
 {
-    const int c = (int)(uint32_t)(key >> 47) - base;
-    return c < 0 ? 0 : (c > PF_BINS - 1 ? PF_BINS - 1 : c);
+    const int c = (int)(uint32_t)(key >> 47);
+    if (feas) return pf_clamp(c - PF_FEAS_BASE, PF_BINS);
+    return c >= 0x10000 ? PF_BINS / 2 + pf_clamp(c - PF_POS_BASE, PF_BINS / 2) : pf_clamp(c - PF_NEG_BASE, PF_BINS / 2);
 }
-// lowest key of bin f (0: everything)
-__device__ __forceinline__ uint64_t pf_edge(int f, int base) { return f <= 0 ? 0ull : (uint64_t)(uint32_t)(base + f) << 47; }
+// lowest key of bin f (bin 0: everything; the lowest bin of the positive half: every key from +0 up)
+__device__ __forceinline__ uint64_t pf_edge(int f, bool feas)
+{
+    if (f <= 0) return 0ull;
+    if (feas) return (uint64_t)(uint32_t)(PF_FEAS_BASE + f) << 47;
+    if (f < PF_BINS / 2) return (uint64_t)(uint32_t)(PF_NEG_BASE + f) << 47;
+    return f == PF_BINS / 2 ? 0x8000000000000000ull : (uint64_t)(uint32_t)(PF_POS_BASE + f - PF_BINS / 2) << 47;
+}
 // word of bin f inside a replica of the global table: consecutive bins in consecutive 128-B lines
 __device__ __forceinline__ int pf_slot(int f) { return (f & 63) * 32 + (f >> 6); }
 
