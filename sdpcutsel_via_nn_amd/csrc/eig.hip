@@ -33,6 +33,7 @@ struct EigArgs {
     int64_t L;
     double *eig_out;
     TopkWs *tk;      // FUSE: leading-digit histogram + violated count of the feasibility selection that follows
+    int32_t spread;  // the four waves of a tile take their strips from four distant quarters of a class's list (see eig_class)
     int32_t pf_mloc; // FUSE: fine histogram of the class (topk_dev.h): a workgroup reports its table down to its pf_mloc-th largest member; 0: off
 };
 
@@ -159,13 +160,15 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
     if (t >= hi) return;      // uniform
     int32_t s_nxt[K];
     int32_t orig_nxt;
-    // (r5) the four waves of a tile work on four DISTANT quarters of the class's list: wave w of tile T takes strip w * ntile + T
-    // (64 consecutive candidates, coalesced as before).  Real covers are enumerated index set by index set: neighbours share
-    // variables and scores, a run rich in head members would otherwise fill a whole tile (pf_retire_keys, topk_dev.h).
+    // (r5) A.spread (one tile per workgroup: most real covers): the four waves of a tile work on four DISTANT quarters of the
+    // class's list -- wave w of tile T takes strip w * ntile + T (64 consecutive candidates, coalesced as before).  Real covers
+    // are enumerated index set by index set: neighbours share variables and scores, a run rich in members of the head would
+    // otherwise fill a whole workgroup (pf_retire_table, topk_dev.h).
     const int64_t ntile = hi - lo;
-    const int64_t wofs = (int64_t)(threadIdx.x >> 6) * ntile * 64 + (threadIdx.x & 63);
+    const int64_t tstep = A.spread ? 64 : 256;
+    const int64_t wofs = A.spread ? (int64_t)(threadIdx.x >> 6) * ntile * 64 + (threadIdx.x & 63) : (int64_t)threadIdx.x;
     {
-        const int64_t c = (t - lo) * 64 + wofs, cc = c < n ? c : n - 1;
+        const int64_t c = (t - lo) * tstep + wofs, cc = c < n ? c : n - 1;
         load_index_set<K>(s_nxt, A.set[K], n, cc);
         orig_nxt = A.orig[K][cc];
     }
@@ -174,9 +177,9 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
         const int32_t out_idx = orig_nxt;
-        const bool valid = (t - lo) * 64 + wofs < n;
+        const bool valid = (t - lo) * tstep + wofs < n;
         if (t + G < hi) {      // uniform
-            const int64_t c = (t + G - lo) * 64 + wofs, cc = c < n ? c : n - 1;
+            const int64_t c = (t + G - lo) * tstep + wofs, cc = c < n ? c : n - 1;
             load_index_set<K>(s_nxt, A.set[K], n, cc);
             orig_nxt = A.orig[K][cc];
         }
@@ -264,6 +267,7 @@ static void eig_launch(sdpcut_ctx *h, EigArgs &A, hipEvent_t ev_start, hipEvent_
         A.pf_mloc = per_wg >= 60000 ? 0 : (m > 60000.0 ? 60000 : (int)(m + 0.999));
     }
 #endif
+    A.spread = A.pf_mloc > 0 && ntiles <= grid;
     if (ev_start || ev_stop)
         hipExtLaunchKernelGGL((eig_only_kernel<KMAX, FUSE>), dim3(grid), dim3(256), 0, h->stream, ev_start, ev_stop, 0, A);
     else
@@ -288,6 +292,7 @@ int launch_eig_only(sdpcut_ctx *h, void *tk, hipEvent_t ev_start, hipEvent_t ev_
     if (kmax == 0) return 0;
     A.vars = h->d_vars; A.nv = h->nb_vars; A.L = h->L; A.eig_out = h->d_eig; A.tk = (TopkWs *)tk;
     A.pf_mloc = 0;      // (set with the grid: eig_launch)
+    A.spread = 0;
 #define EIG_LAUNCH(KM)                                                   \
     do {                                                                 \
         if (tk) eig_launch<KM, true>(h, A, ev_start, ev_stop, pf_k);     \

@@ -57,6 +57,7 @@ struct ScoreArgs {
     // the selection never looks below the class.
     TopkWs *tk;
     int tk_mode;           // TK_MODE_FEAS / OPT / STRONG: the kernel's FUSE template argument
+    int32_t spread;        // the four waves of a workgroup take strips from four distant quarters of the list (see score_mfma_body)
     int32_t pf_mloc;       // fine histogram of the class (topk_dev.h): a workgroup reports its table down to its pf_mloc-th largest member; 0: off
     // optional: += number of candidates with obj_improve > 0 and lambda_min < -1e-15 (the "strong" class
     // of the combined strategy, cut_select_qp.py:607-613); lets the selection that follows pick its
@@ -513,12 +514,14 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     //    not pay: a single-tile pass of a lone wave takes as long as a two-tile pass, profiles/r03_k3_kernel_time_vs_list_length.txt.)
     // The last strip of a list may hold fewer candidates: it runs the passes its column tiles need, the last one over a single
     // tile if their number is odd (mlp_pass<1>: the same arithmetic per candidate, bit-equal scores).
-    // (r5) ... no longer: wave w of workgroup b is wave w * nblk + b of the launch -- the four waves of a workgroup work on four DISTANT
-    // quarters of the list (the resident workgroups still move through each quarter together: four streams instead of one).  Real
-    // covers are enumerated index set by index set, neighbours share variables and scores: a run of consecutive candidates rich in
-    // members of the head would otherwise fill a whole workgroup, which then reports fewer of them than it holds and sends the
-    // selection through its radix passes (pf_retire_table, topk_dev.h).  Scores do not depend on who computes them.
-    const int64_t gw = (int64_t)wave * nblk + bid;
+    // (r5) A.spread (lists of ONE strip per wave -- most real covers): wave w of workgroup b is wave w * nblk + b of the launch, the
+    // four waves of a workgroup work on four DISTANT quarters of the list.  Real covers are enumerated index set by index set,
+    // neighbours share variables and scores: 256 consecutive candidates rich in members of the head would otherwise be one
+    // workgroup's whole share, which then reports fewer of them than it holds and sends the selection through its radix passes
+    // (pf_retire_table, topk_dev.h; 13 of 191 recorded rounds).  Longer lists keep the consecutive strips (a workgroup's share
+    // already comes from several rounds of the list; spreading its waves cost the 10^6-candidate launch 3 us).  Scores do not
+    // depend on who computes them.
+    const int64_t gw = A.spread ? (int64_t)wave * nblk + bid : (int64_t)bid * 4 + wave;
     const int64_t wstride = (int64_t)nblk * 4 * A.strip;      // candidates between two strips of one wave
     const int64_t c_first = gw * A.strip;
     // ... and the LAST round of a list of a few rounds, when it is nearly full (r4): 10^6 candidates are 7.63 strips per resident
@@ -1304,6 +1307,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
     A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
     A.tk_mode = fuse ? fuse->mode : 0;
     A.pf_mloc = 0;      // (set with the grid below)
+    A.spread = 0;
     A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
     A.net = h->net[K].dev;
     if ((flags & SDPCUT_NN) && !h->net[K].set)
@@ -1325,6 +1329,7 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
         }
         set_balanced_tail(A, grid);
         A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
+        A.spread = A.pf_mloc > 0 && b.n <= (int64_t)grid * 4 * A.strip;
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
@@ -1392,6 +1397,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
         A.tk = fuse ? (TopkWs *)fuse->ws : nullptr;
         A.tk_mode = f;
         A.pf_mloc = 0;
+        A.spread = 0;
         A.strong_out = ((flags & SDPCUT_EIG) && (flags & SDPCUT_NN)) ? strong_out : nullptr;
         A.net = h->net[k].dev;
         int grid = grid_for(h, (b.n + 255) / 256, SDPCUT_MFMA_BLOCKS_PER_CU);
@@ -1401,6 +1407,7 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
         }
         set_balanced_tail(A, grid);
         A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
+        A.spread = A.pf_mloc > 0 && b.n <= (int64_t)grid * 4 * A.strip;
         blocks += grid;
         AA.k[i] = k;
         AA.bend[i] = (int32_t)blocks;

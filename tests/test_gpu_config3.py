@@ -67,6 +67,8 @@ ADMITTED_PAIRS = {
     # obj_improve + 1000 (cut_select_qp.py:611): the reference's own obj_improve of the two members differ by 3.4e-13 / by nothing,
     # the device's MLP (MFMA summation order) is 1e-13 .. 1e-12 from NNs.so on them -- 1e-15 of the score, BASELINE grants 1e-6
     ("rounds_spar125_075_2_d3_s4", 2): [(41980, 110560), (98522, 87399)],
+    # exact eigenvalues 2.9e-17 apart; the reference's LAPACK is 1.7e-16 and 2.0e-16 from them, csrc/lmin.h 0.7e-16 and 2.2e-16
+    ("rounds_spar125_075_2_d3_s4", 18): [(3688, 42018)],
     # third LP of the pure-feasibility run: six pairs of EXACTLY equal eigenvalues (permuted copies), 1e-16 apart in LAPACK
     ("rounds_spar080_075_1_d4_s1", 3): [(51053, 57454), (80443, 223334), (185697, 126667), (207046, 206215), (223365, 80472),
                                         (234718, 222031)],
@@ -202,11 +204,11 @@ def test_replay_of_the_reference_trajectory(path, oracle):
             extra = []
             if not same.all():
                 key = (base, r)
-                assert key in ADMITTED_PAIRS or key in STRUCTURED_ROUNDS, \
-                    "%s round %d must reproduce the reference's head position by position: %d positions differ (%s)" % (
-                        base, r, int((~same).sum()), np.flatnonzero(~same)[:10].tolist())
                 pairs, extra = _explain_inversions(oracle, sc, inst, g, r, strat, res, ref_ids, ref_score)
                 _append_report(["%s round %d (strategy %d): inverted pairs %s" % (base, r, strat, pairs)] + extra)
+                assert key in ADMITTED_PAIRS or key in STRUCTURED_ROUNDS, \
+                    "%s round %d must reproduce the reference's head position by position: %d positions differ (%s); pairs %s" % (
+                        base, r, int((~same).sum()), np.flatnonzero(~same)[:10].tolist(), pairs)
                 if key in ADMITTED_PAIRS:
                     assert n_set == 0, (r, n_set)
                     want = ADMITTED_PAIRS[key]
