@@ -1000,6 +1000,14 @@ def main():
 
 
 def main_c3(args):
+    if args.no_prefilter:      # A/B: every handle the drop-in classes make runs without the fine histogram (same results either way)
+        from sdpcutsel_via_nn_amd import _capi
+        plain_init = _capi.Scorer.__init__
+
+        def init_without(self, *a, **kw):
+            plain_init(self, *a, **kw)
+            self.set_option(_capi.OPT_PREFILTER, 0)
+        _capi.Scorer.__init__ = init_without
     """--config c3: the spar125-075-1 dim-4 rounds as the line's workload (one GPU).  value = candidates per second
     through the drop-in pair with the combined strategy (every candidate scored eig + NN, the round ranked and its
     cuts handed to the LP's row store); the other routes and the feasibility point ride along in `c3`."""

@@ -164,11 +164,14 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
     // class's list -- wave w of tile T takes strip w * ntile + T (64 consecutive candidates, coalesced as before).  Real covers
     // are enumerated index set by index set: neighbours share variables and scores, a run rich in members of the head would
     // otherwise fill a whole workgroup (pf_retire_table, topk_dev.h).
-    const int64_t ntile = hi - lo;
-    const int64_t tstep = A.spread ? 64 : 256;
-    const int64_t wofs = A.spread ? (int64_t)(threadIdx.x >> 6) * ntile * 64 + (threadIdx.x & 63) : (int64_t)threadIdx.x;
+    // (32-bit index arithmetic, recomputed per tile: the kernel has no registers to spare -- three 64-bit values kept across the
+    // tile loop cost the 3- and 4-variable instantiations 4 and 17 more spilled registers)
+    auto cand_of = [&](int64_t tile) -> int {
+        const int tl = (int)(tile - lo);
+        return A.spread ? ((int)(threadIdx.x >> 6) * (int)(hi - lo) + tl) * 64 + (int)(threadIdx.x & 63) : tl * 256 + (int)threadIdx.x;
+    };
     {
-        const int64_t c = (t - lo) * tstep + wofs, cc = c < n ? c : n - 1;
+        const int c = cand_of(t), cc = c < n ? c : (int)n - 1;
         load_index_set<K>(s_nxt, A.set[K], n, cc);
         orig_nxt = A.orig[K][cc];
     }
@@ -177,9 +180,9 @@ __device__ __forceinline__ void eig_class(const EigArgs &A, int64_t lo, int64_t 
 #pragma unroll
         for (int a = 0; a < K; ++a) s_cur[a] = s_nxt[a];
         const int32_t out_idx = orig_nxt;
-        const bool valid = (t - lo) * tstep + wofs < n;
+        const bool valid = cand_of(t) < n;
         if (t + G < hi) {      // uniform
-            const int64_t c = (t + G - lo) * tstep + wofs, cc = c < n ? c : n - 1;
+            const int c = cand_of(t + G), cc = c < n ? c : (int)n - 1;
             load_index_set<K>(s_nxt, A.set[K], n, cc);
             orig_nxt = A.orig[K][cc];
         }
