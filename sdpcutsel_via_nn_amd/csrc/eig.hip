@@ -71,8 +71,7 @@ constexpr int eig_pack_doubles(int kmax)
 #endif
 
 template <int K, bool FUSE>
-__device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol,
-                                         int *pf_out = nullptr)      // (pf_out: unused)
+__device__ __forceinline__ void eig_emit(const EigArgs &A, double lam, int32_t out_idx, bool live, uint32_t *tk_hist, uint32_t &c_viol)
 {
     if (live) A.eig_out[out_idx] = lam;
     if constexpr (FUSE) {

@@ -81,3 +81,50 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode != 0 and b"WORLD_SIZE=2" in out.stderr
+
+
+def test_fine_histogram_window_arithmetic():
+    """numpy twin of pf_code / pf_edge (csrc/topk_dev.h): the window code is monotone in the key, every key lies in [edge(code),
+    edge(code + 1)), the feasibility window holds -lambda_min in (1e-15, 8], the obj_improve window both signs.  (The constants are
+    read from the header so that the twin cannot drift.)"""
+    import re
+    import struct
+    hdr = open(os.path.join(ROOT, "sdpcutsel_via_nn_amd", "csrc", "topk_dev.h")).read()
+    PF = int(re.search(r"#define PF_BINS (\d+)", hdr).group(1))
+    assert PF == 2048 and "PF_FEAS_BASE (0x10000 + ((1023 + 8) << 5) - PF_BINS)" in hdr
+    assert "PF_POS_BASE (0x10000 + ((1023 - 16) << 5))" in hdr and "PF_NEG_BASE (0xFFFF - ((1023 + 16) << 5) + 1)" in hdr
+    FE, PO, NE = 0x10000 + ((1023 + 8) << 5) - PF, 0x10000 + ((1023 - 16) << 5), 0xFFFF - ((1023 + 16) << 5) + 1
+
+    def key_of(x):      # csrc/keys.h
+        u = struct.unpack("<Q", struct.pack("<d", x + 0.0))[0]
+        return (~u) & 0xFFFFFFFFFFFFFFFF if u >> 63 else u | (1 << 63)
+
+    def clamp(c, n):
+        return 0 if c < 0 else (n - 1 if c > n - 1 else c)
+
+    def code(x, feas):
+        c = key_of(x) >> 47
+        if feas:
+            return clamp(c - FE, PF)
+        return PF // 2 + clamp(c - PO, PF // 2) if c >= 0x10000 else clamp(c - NE, PF // 2)
+
+    def edge(f, feas):
+        if f <= 0:
+            return 0
+        if feas:
+            return (FE + f) << 47
+        if f < PF // 2:
+            return (NE + f) << 47
+        return 1 << 63 if f == PF // 2 else (PO + f - PF // 2) << 47
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(size=20000) * 10.0 ** rng.uniform(-8, 6, 20000),
+                         [0.0, -0.0, 1e-300, -1e-300, 2.0 ** 16, 2.0 ** -16, -2.0 ** 16, -2.0 ** -16, 65535.9, -65535.9, 1e-15, 8.0]])
+    for feas in (False, True):
+        ks = [key_of(float(x)) for x in xs]
+        cs = [code(float(x), feas) for x in xs]
+        order = np.argsort(np.array(ks, dtype=np.uint64))
+        assert all(cs[order[i]] <= cs[order[i + 1]] for i in range(len(order) - 1))
+        for k, c in zip(ks, cs):
+            assert k >= edge(c, feas) and (c == PF - 1 or k < edge(c + 1, feas))
+    assert 0 < code(1e-15, True) < code(8.0, True) < PF - 1                  # the whole range of a feasibility score inside the window
+    assert code(-1.0, False) < PF // 2 <= code(0.0, False) < code(1.0, False)

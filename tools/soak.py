@@ -2,7 +2,9 @@
 """Soak run on the GPU box: thousands of back-to-back fused rounds over changing points (random
 LP-like points and structured points whose masses of equal eigenvalues drive the radix select
 through all eight digits inside the grid barrier), strategies, head lengths and list sizes.
-Every result must be bit-identical to the first one of its kind.
+Every result must be bit-identical to the first one of its kind -- and (r5) the first one of a kind on the main and on the
+mixed-size handle is computed with SDPCUT_OPT_PREFILTER off: every later round, resolved from the fine histogram wherever that
+applies, is thereby compared with what the radix passes return.
 Usage: python tools/soak.py [seconds=120] [count=1000000]"""
 import os
 import sys
@@ -90,7 +92,11 @@ def main():
                 got3 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r3.items()}
                 mixed += 1
                 if key3 not in first:
-                    first[key3] = got3
+                    sc3.set_option(_capi.OPT_PREFILTER, 0)
+                    r3 = sc3.round_csr(strat3, sel3, point=points[p3])
+                    sc3.set_option(_capi.OPT_PREFILTER, 1)
+                    first[key3] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r3.items()}
+                if True:
                 else:
                     for k, v in got3.items():
                         same = np.array_equal(v, first[key3][k], equal_nan=True) if isinstance(v, np.ndarray) else v == first[key3][k]
@@ -101,9 +107,15 @@ def main():
             got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
             rounds += 1
             per_kind[key] = per_kind.get(key, 0) + 1
-            if key not in first:
-                first[key] = got
-                continue
+            if key not in first:      # the reference of this kind: the same round through the radix passes
+                sc.set_option(_capi.OPT_PREFILTER, 0)
+                if csr:
+                    rr = sc.round_csr(strat, sel, point=points[p])
+                else:
+                    sc.set_point(points[p])
+                    rr = sc.select_round(strat, sel, copy=False)
+                sc.set_option(_capi.OPT_PREFILTER, 1)
+                first[key] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in rr.items()}
             ref = first[key]
             for k, v in got.items():
                 same = np.array_equal(v, ref[k], equal_nan=True) if isinstance(v, np.ndarray) else v == ref[k]
@@ -114,11 +126,13 @@ def main():
             print("%d rounds, %d kinds, all identical so far" % (rounds, len(first)), flush=True)
     fallbacks = sc.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc2.get_stat(_capi.STAT_SELECT_FALLBACKS) + sc3.get_stat(_capi.STAT_SELECT_FALLBACKS)
     splits = [s_.get_stat(_capi.STAT_TIE_SPLITS) for s_ in (sc, sc2, sc3)]
+    direct = [s_.get_stat(_capi.STAT_DIRECT_SELECTIONS) for s_ in (sc, sc2, sc3)]
     print("soak ok: %d rounds over %d kinds (sizes %s, %d points, strategies 1/2/4, both epilogues; %d of them begun together with a round "
           "on a second handle and ended after it; + %d rounds on a list of mixed sizes 2..5), every repeat bit-identical; %d rounds answered by the "
           "full-sort path (SDPCUT_STAT_SELECT_FALLBACKS); %d / %d / %d rounds (first / second handle / mixed list) whose threshold tie group was "
-          "cut by its secondary key (SDPCUT_STAT_TIE_SPLITS)"
-          % (rounds, len(first), sizes, len(points), pairs, mixed, fallbacks, splits[0], splits[1], splits[2]))
+          "cut by its secondary key (SDPCUT_STAT_TIE_SPLITS); %d / %d / %d selections resolved from the fine histogram without a digit "
+          "pass (SDPCUT_STAT_DIRECT_SELECTIONS), each compared with the radix passes' result of its kind"
+          % (rounds, len(first), sizes, len(points), pairs, mixed, fallbacks, splits[0], splits[1], splits[2], direct[0], direct[1], direct[2]))
     sc.close()
     sc2.close()
     sc3.close()
