@@ -96,13 +96,11 @@ def main():
                     r3 = sc3.round_csr(strat3, sel3, point=points[p3])
                     sc3.set_option(_capi.OPT_PREFILTER, 1)
                     first[key3] = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r3.items()}
-                if True:
-                else:
-                    for k, v in got3.items():
-                        same = np.array_equal(v, first[key3][k], equal_nan=True) if isinstance(v, np.ndarray) else v == first[key3][k]
-                        if not same:
-                            print("MISMATCH round %d kind %s field %s" % (rounds, key3, k), flush=True)
-                            sys.exit(1)
+                for k, v in got3.items():
+                    same = np.array_equal(v, first[key3][k], equal_nan=True) if isinstance(v, np.ndarray) else v == first[key3][k]
+                    if not same:
+                        print("MISMATCH round %d kind %s field %s" % (rounds, key3, k), flush=True)
+                        sys.exit(1)
             key = (size, p, strat, sel, csr)
             got = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()}
             rounds += 1
