@@ -512,6 +512,45 @@ def bench_opt_only(make_scorer, K, n_local, vv_host, steps, gpu_rounds=None):
             "kernel_ms": k_ms, "achieved_TFLOPs": tflops, "roofline_frac": tflops / FP64_PEAK_TFLOPS}
 
 
+def bench_cold_round(make_scorer, K, n_local, vv_host, repeats=20):
+    """What a round costs when the device has been IDLE -- in the reference's loop a separation round follows an LP solve of
+    0.1-10 s (cut_select_qp.py:149-200), not the previous round.  Median host-to-host time of one combined and one feasibility
+    round on the main workload after the process slept 10 ms / 100 ms / 1 s (no GPU work in between), `repeats` times each, next
+    to the same round issued back to back; and the same with a cheap mitigation measured: a one-workgroup kernel launched
+    when the sleep ends, i.e. while a caller would still be copying the LP solution (`_poked`)."""
+    import torch
+    sc, _, _, _ = make_scorer(K, n_local, 7, 0)
+    out = {"repeats": repeats, "unit": "ms host to host, median", "workload": "the main list, sel_size %d" % SEL}
+    poke = torch.zeros(64, device="cuda")
+    for strat, name in ((4, "combined"), (1, "feasibility")):
+        for _ in range(30):
+            sc.select_round(strat, SEL, copy=False, point=vv_host)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            sc.select_round(strat, SEL, copy=False, point=vv_host)
+            ts.append(time.perf_counter() - t0)
+        rec = {"back_to_back": float(np.median(ts)) * 1e3}
+        for idle in (0.01, 0.1, 1.0):
+            for poked in (False, True):
+                ts = []
+                for _ in range(repeats):
+                    time.sleep(idle)
+                    if poked:      # a trivial kernel as soon as the LP solve returns; the round follows ~20 us later (the point's copy)
+                        poke.add_(1.0)
+                        t_p = time.perf_counter()
+                        while time.perf_counter() - t_p < 20e-6:
+                            pass
+                    t0 = time.perf_counter()
+                    sc.select_round(strat, SEL, copy=False, point=vv_host)
+                    ts.append(time.perf_counter() - t0)
+                rec["idle_%g_ms%s" % (idle * 1e3, "_poked" if poked else "")] = float(np.median(ts)) * 1e3
+        out[name] = rec
+    sc.close()
+    return out
+
+
 class _StdoutToStderr(object):
     """fd-level redirect: native libraries (RCCL prints a version banner when its first communicator
     comes up) must not put lines on stdout, which carries exactly one JSON line."""
@@ -656,6 +695,7 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip secondary.c3 / c5 (the spar125-075-1 dim-4 rounds, the q_50 QCQP round) of the default run")
     ap.add_argument("--kernel", choices=["mfma", "simple", "valu"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip secondary.cold_round (rounds after 10 ms / 100 ms / 1 s of idle device: ~50 s)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the k = 2, 4, 5 single-GPU rates")
     ap.add_argument("--device-point", action="store_true",
                     help="A/B: take the LP point from a device buffer (the round-1 bracket) instead of host memory")
@@ -965,6 +1005,8 @@ def main():
             # the feasibility round (strategy 1, cut_select_qp.py:639-654) on the same list: the eigenvalue-only kernel
             out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
             out["secondary"]["strategy_2"] = bench_opt_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
+            if not args.no_cold:
+                out["secondary"]["cold_round"] = bench_cold_round(make_scorer, K, n_local, vv_host)
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rounds on the c3 cover (spar125-075-1 dim 4, bench.py's setup) through ONE route and ONE strategy, for profiling:
 
-    tools/c3_rounds.py <fused_rows|fused_csr|dropin_pair> <4|1> [steps] [--cprofile] [--legacy]
+    tools/c3_rounds.py <fused_rows|fused_csr|dropin_pair> <4|1> [steps] [--cprofile] [--legacy] [--round R]
 
 prints ms per round; --cprofile adds the host-side profile of the route; --legacy makes the drop-in pair take the
 round-2 route (rank + sdpcut_cut_rows + host assembly of the CSR block) for before/after comparisons."""
@@ -23,6 +23,12 @@ def main():
         from sdpcutsel_via_nn_amd import cut_solver
         cut_solver._FUSED_HEAD_MAX = 0
     vv = pts[strat]
+    if "--round" in sys.argv:      # the LP point the reference's trajectory recorded for round R (tests/golden) instead of bench.py's choice
+        import numpy as np
+        r = int(sys.argv[sys.argv.index("--round") + 1])
+        g = np.load(os.path.join(bench.ROOT, "tests", "golden", "rounds_%s_d%d_s4.npz" % (bench.C3_INSTANCE.replace("-", "_"), bench.C3_DIM)))
+        assert int(g["r%02d_strat" % r]) == strat, "round %d of the recorded trajectory ran strategy %d" % (r, int(g["r%02d_strat" % r]))
+        vv = np.ascontiguousarray(g["r%02d_vars" % r], dtype=np.float64)
     for _ in range(30):
         cuts = f(strat, vv)
     torch.cuda.synchronize()

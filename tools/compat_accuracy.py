@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The reference's FFI on the product library (neural_net_kD of libsdpcut_hip.so, csrc/compat.hip) against the values the
+"""The reference's FFI on the product library (neural_net_kD of libsdpcut_nns.so, csrc/nns_compat.cpp) against the values the
 real NNs.so returned for the same inputs (tests/golden/nn_k*.npz): max / median relative difference per network."""
 import ctypes
 import os
@@ -12,7 +12,7 @@ from sdpcutsel_via_nn_amd import _capi  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 _capi.load_library()
-lib = ctypes.cdll.LoadLibrary(_capi.LIB_PATH)
+lib = ctypes.cdll.LoadLibrary(_capi.NNS_LIB_PATH)
 for d in (2, 3, 4, 5):
     f = getattr(lib, "neural_net_%dD" % d)
     f.restype = ctypes.c_double

@@ -2,8 +2,8 @@ set -o pipefail
 export TMPDIR=/tmp
 # A/B of the fine histogram (SDPCUT_OPT_PREFILTER) on one box: the default bench twice each way, the c3 rounds each way, a kernel timeline
 for i in 1 2; do
-timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-c3 --no-cpu-baseline > gpurun_out/r05_bench_d_on$i.json 2> gpurun_out/r05_bench_d.err || exit 1
-timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-c3 --no-cpu-baseline --no-prefilter > gpurun_out/r05_bench_d_off$i.json 2>> gpurun_out/r05_bench_d.err || exit 1
+timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-c3 --no-cold --no-cpu-baseline > gpurun_out/r05_bench_d_on$i.json 2> gpurun_out/r05_bench_d.err || exit 1
+timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-c3 --no-cold --no-cpu-baseline --no-prefilter > gpurun_out/r05_bench_d_off$i.json 2>> gpurun_out/r05_bench_d.err || exit 1
 done
 timeout -k 10 200 python bench.py --config c3 --steps 60 > gpurun_out/r05_c3_on.json 2>> gpurun_out/r05_bench_d.err || exit 1
 timeout -k 10 200 python bench.py --config c3 --steps 60 --no-prefilter > gpurun_out/r05_c3_off.json 2>> gpurun_out/r05_bench_d.err || exit 1
