@@ -516,12 +516,11 @@ def bench_cold_round(make_scorer, K, n_local, vv_host, repeats=20):
     """What a round costs when the device has been IDLE -- in the reference's loop a separation round follows an LP solve of
     0.1-10 s (cut_select_qp.py:149-200), not the previous round.  Median host-to-host time of one combined and one feasibility
     round on the main workload after the process slept 10 ms / 100 ms / 1 s (no GPU work in between), `repeats` times each, next
-    to the same round issued back to back; and the same with a cheap mitigation measured: a one-workgroup kernel launched
-    when the sleep ends, i.e. while a caller would still be copying the LP solution (`_poked`)."""
+    to the same round issued back to back; and the same with a cheap mitigation measured: sdpcut_wake -- an empty kernel --
+    issued when the sleep ends, i.e. while a caller would still be copying the LP solution (`_poked`)."""
     import torch
     sc, _, _, _ = make_scorer(K, n_local, 7, 0)
     out = {"repeats": repeats, "unit": "ms host to host, median", "workload": "the main list, sel_size %d" % SEL}
-    poke = torch.zeros(64, device="cuda")
     for strat, name in ((4, "combined"), (1, "feasibility")):
         for _ in range(30):
             sc.select_round(strat, SEL, copy=False, point=vv_host)
@@ -537,8 +536,8 @@ def bench_cold_round(make_scorer, K, n_local, vv_host, repeats=20):
                 ts = []
                 for _ in range(repeats):
                     time.sleep(idle)
-                    if poked:      # a trivial kernel as soon as the LP solve returns; the round follows ~20 us later (the point's copy)
-                        poke.add_(1.0)
+                    if poked:      # sdpcut_wake as soon as the LP solve returns; the round follows ~20 us later (the point's copy)
+                        sc.wake()
                         t_p = time.perf_counter()
                         while time.perf_counter() - t_p < 20e-6:
                             pass
@@ -572,9 +571,9 @@ class _StdoutToStderr(object):
 ISSUE_CYCLES_PER_CAND = {
     # (r4, Householder + Laguerre lambda_min) VALU instructions per launch, of which quarter-rate transcendentals, MFMAs:
     ("eig", 3): ((8.065 - 0.229) * 4 + 0.229 * 16, "profiles/r04_eig_k3_kernel_pmc.txt (8.065 M VALU of which 0.229 M v_rsq / v_rcp_f64; round 3, Jacobi: 18.67 M)"),
-    ("mfma", 3): ((72.312 - 1.015) * 4 + 1.015 * 16 + 5.4375 * 64, "profiles/r04_k3_score_kernel_pmc.txt (72.31 M VALU of which 1.015 M transcendental + 5.4375 M MFMA "
-                                                                   "per launch = 4628 + 348 per 64 candidates, the partial strips of the balanced last round included; "
-                                                                   "round 3: 83.71 M VALU = 5357 per strip)"),
+    ("mfma", 3): ((73.737 - 1.015) * 4 + 1.015 * 16 + 5.4375 * 64, "profiles/r05_k3_score_kernel_pmc.txt (73.74 M VALU of which 1.015 M transcendental + 5.4375 M MFMA "
+                                                                   "per launch = 4719 + 348 per 64 candidates, the partial strips of the balanced last round and the "
+                                                                   "fine histogram of the selection's class included; round 4: 72.31 M VALU, round 3: 83.71 M)"),
 }
 SIMDS, CLOCK_GHZ = 1024, 2.4
 

@@ -140,6 +140,11 @@ int sdpcut_set_option(sdpcut_handle h, int option, int64_t value);
 #define SDPCUT_OWN_STREAM ((void *)(intptr_t)-1)
 int sdpcut_set_stream(sdpcut_handle h, void *hip_stream);
 int sdpcut_synchronize(sdpcut_handle h);
+/* (r5) Enqueue an empty kernel on the handle's stream and return at once.  In the reference's loop a separation round follows an LP
+ * solve of 0.1-10 s (cut_select_qp.py:149-200, :193-200) during which the device falls idle; a round issued to an idle device costs
+ * 0.1-0.2 ms more than one issued back to back (bench.py: secondary.cold_round).  A caller that pokes the device as soon as its
+ * solver returns -- before it extracts the solution vector -- gets 40-65 us of that back.  Optional; changes no result. */
+int sdpcut_wake(sdpcut_handle h);
 
 /*
  * Trained MLP for k-variable candidates (replaces the constants baked into NNs.so;

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sdpcut_set_stream": [_vp, _vp],
     "sdpcut_get_stat": [_vp, _c.c_int, _i64p],
     "sdpcut_synchronize": [_vp],
+    "sdpcut_wake": [_vp],
     "sdpcut_set_network": [_vp, _c.c_int, _c.c_int, _i32p, _dp, _c.c_int64],
     "sdpcut_set_instance": [_vp, _c.c_int32, _dp],
     "sdpcut_set_candidates": [_vp, _c.c_int64, _i32p, _c.c_int32, _i32p, _c.c_int64],
@@ -220,6 +221,10 @@ class Scorer(object):
         v = _c.c_int64(0)
         self._check(self._lib.sdpcut_get_stat(self._h, int(which), ctypes.byref(v)))
         return int(v.value)
+
+    def wake(self):
+        """an empty kernel on the handle's stream (sdpcut_wake): poke an idle device while the LP solution is still being extracted"""
+        self._check(self._lib.sdpcut_wake(self._h))
 
     def synchronize(self):
         self._check(self._lib.sdpcut_synchronize(self._h))

@@ -318,6 +318,17 @@ int sdpcut_set_stream(sdpcut_handle h, void *hip_stream)
     return SDPCUT_OK;
 }
 
+static __global__ void wake_kernel() {}
+
+int sdpcut_wake(sdpcut_handle h)
+{
+    if (!h) return SDPCUT_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return SDPCUT_OK;
+}
+
 int sdpcut_synchronize(sdpcut_handle h)
 {
     if (!h) return SDPCUT_EINVAL;

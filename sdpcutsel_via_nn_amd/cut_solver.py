@@ -485,6 +485,14 @@ class GpuCutSelectionMixin(object):
         self._nns = [(None, None)] * (self._dim - 1)
         self._gpu_bindings = {}
 
+    def _gpu_wake(self):
+        """Poke the device(s) of the bound candidate lists (sdpcut_wake): called the moment an LP solve returns, while the solution
+        vector is still being extracted -- a round issued to a device that idled through the solve costs 0.1-0.2 ms more than one
+        issued back to back, and this gets 40-65 us of it back (bench.py: secondary.cold_round).  A maintainer of the reference's
+        own loop adds `self._gpu_wake()` behind `my_prob.solve()` (cut_select_qp.py:194); optional, changes no result."""
+        for b in getattr(self, "_gpu_bindings", {}).values():
+            b.scorer.wake()
+
     # ------------------------------------------------------------------ device binding
     def _gpu_new_scorer(self):
         sc = _capi.Scorer(self._gpu_device)
@@ -970,7 +978,8 @@ class CutSolver(GpuCutSelectionMixin):
             return {"sdp": sdp, "tri": tri}
 
         log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts, setup_s=t_model,
-                                     stop_tol=self._CONVERGENCE_TOL if term_on else None, on_round=on_round)
+                                     stop_tol=self._CONVERGENCE_TOL if term_on else None, on_round=on_round,
+                                     after_solve=self._gpu_wake)
         sep = [t_model] + log.separation_s
         return ([-v for v in log.bounds], clock() - t_start, [a + b for a, b in zip(log.solve_s, [0.0] + log.separation_s)],
                 sep, [0] + log.column("sdp"), log.column("tri"), n_cand)
@@ -1048,7 +1057,7 @@ class CutSolverQCQP(CutSolver):
                                                                          cover_obj, cover_cons)
             return {"sdp": sdp, "opt": opt}
 
-        log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts)
+        log = harness.run_cut_rounds(lp, separate, nb_rounds_cuts, after_solve=self._gpu_wake)
         opt = log.column("opt")
         return log.bounds, quota, [0] + log.column("sdp"), [0] + opt + [0] * (nb_rounds_cuts - len(opt))
 

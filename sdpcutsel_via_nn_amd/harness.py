@@ -303,11 +303,12 @@ class RoundLog(object):
         return len(b) >= 3 and b[-1] != b[0] and (b[-1] - b[-2]) / (b[-1] - b[0]) < tol
 
 
-def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=None, on_round=None):
+def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=None, on_round=None, after_solve=None):
     """Drive ``max_rounds`` rounds on ``lp`` (anything with solve / get_values /
     get_objective_value): ``separate(round_no, point) -> dict of counts`` appends cuts to the LP
     between two solves.  ``setup_s`` is added to the first solve's time (model building).
-    ``on_round(round_no, log)`` is called after every solve (progress of long runs).
+    ``on_round(round_no, log)`` is called after every solve (progress of long runs); ``after_solve()`` the moment a solve
+    returns, before the solution vector is extracted (the GPU classes poke the idle device there: sdpcut_wake).
     -> RoundLog."""
     from timeit import default_timer
     clock = clock or default_timer
@@ -316,6 +317,8 @@ def run_cut_rounds(lp, separate, max_rounds, setup_s=0.0, stop_tol=None, clock=N
     def solve():
         t = clock()
         lp.solve()
+        if after_solve:
+            after_solve()
         log.solve_s.append(clock() - t)
         log.bounds.append(lp.get_objective_value())
         return np.asarray(lp.get_values(), dtype=np.float64)

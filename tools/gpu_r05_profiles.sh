@@ -29,7 +29,7 @@ b)
       i=$((i+1))
       rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/pmc_r05_c3r${r}_$i -o pmc -- python3 tools/c3_rounds.py fused_csr 4 30 --round $r > $out/pmc_r05_c3r${r}_$i.log 2>&1 || { tail -5 $out/pmc_r05_c3r${r}_$i.log; exit 1; }
     done
-    python3 tools/pmc_summary.py score_mfma_all $out/pmc_r05_c3r${r}_1 $out/pmc_r05_c3r${r}_2 $out/pmc_r05_c3r${r}_3 > $out/r05_c3_round${r}_score_kernel_pmc.txt
+    python3 tools/pmc_summary.py "score_mfma_kernel<4" $out/pmc_r05_c3r${r}_1 $out/pmc_r05_c3r${r}_2 $out/pmc_r05_c3r${r}_3 > $out/r05_c3_round${r}_score_kernel_pmc.txt
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_r05_c3r$r -o prof -- python3 tools/c3_rounds.py fused_csr 4 60 --round $r > $out/r05_c3_round${r}_rounds.txt 2> $out/prof_r05_c3r$r.err
     python3 tools/timeline_rounds.py $out/prof_r05_c3r$r 1 >> $out/r05_c3_round${r}_rounds.txt
   done
