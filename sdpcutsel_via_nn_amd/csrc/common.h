@@ -91,6 +91,7 @@ struct sdpcut_ctx {
     bool auto_regime = true;       // SDPCUT_OPT_AUTO_REGIME
     bool fused_tail = true;        // SDPCUT_OPT_FUSED_TAIL
     bool eig_kernel = true;        // SDPCUT_OPT_EIG_KERNEL: eigenvalue-only launches run eig_only_kernel (eig.hip)
+    bool pf_counted = false;       // the scoring launches of the current round all counted the fine histogram (launch_score)
     bool prefilter = true;         // SDPCUT_OPT_PREFILTER: fine histogram in the score kernels, direct selection (topk_dev.h)
     unsigned long long *d_stats = nullptr;   // device counters that outlive a round: [0] direct selections
     bool coop_launch = false;      // SDPCUT_OPT_COOP_LAUNCH: cooperative launch of the kernels with grid barriers (+20 us per round)

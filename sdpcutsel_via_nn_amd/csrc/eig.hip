@@ -270,6 +270,7 @@ static void eig_launch(sdpcut_ctx *h, EigArgs &A, hipEvent_t ev_start, hipEvent_
     }
 #endif
     A.spread = A.pf_mloc > 0 && ntiles <= grid;
+    if (FUSE && A.pf_mloc == 0) h->pf_counted = false;
     if (ev_start || ev_stop)
         hipExtLaunchKernelGGL((eig_only_kernel<KMAX, FUSE>), dim3(grid), dim3(256), 0, h->stream, ev_start, ev_stop, 0, A);
     else

@@ -461,6 +461,9 @@ __device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], c
 constexpr int mfma_cols(int K) { return K == 2 ? SDPCUT_MFMA_J_K2 : K == 3 ? SDPCUT_MFMA_J_K3 : K == 4 ? SDPCUT_MFMA_J_K4 : SDPCUT_MFMA_J_K5; }
 
 // LDS of one workgroup of the MFMA kernel for size class K (a union of these serves the launch over all classes)
+#ifndef SDPCUT_PF_SCORE_MAXK
+#define SDPCUT_PF_SCORE_MAXK 3      // largest candidate size whose score kernel counts the fine histogram (0: none; see score_mfma_body)
+#endif
 template <int K, int H, int NH>
 struct MfmaLds {
     static constexpr int S0 = (K + K * (K + 1) / 2 + 3) / 4;
@@ -474,7 +477,7 @@ struct MfmaLds {
     uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
     uint32_t tk_cnt[2];
     uint32_t s_strong;
-    uint32_t pf_tab[PF_BINS / 2];    // (r5) the class members by window code, 16-bit counters, two per word (topk_dev.h)
+    uint32_t pf_tab[K <= SDPCUT_PF_SCORE_MAXK ? PF_BINS / 2 : 1];    // (r5) the class members by window code, 16-bit counters, two per word (topk_dev.h)
 };
 
 // bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
@@ -568,12 +571,19 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     auto &tk_hist = S.tk_hist;
     auto &tk_cnt = S.tk_cnt;
     uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
+    // (r5) the fine histogram of the selection's class (topk_dev.h) is compiled into the kernels of 2- and 3-variable candidates only:
+    // merely present -- not executed -- it costs the 4-variable kernel 11 us on the 1.7e6-candidate cover of spar125-075-1 (240
+    // registers, 112 bytes of scratch: the allocation of its hot loop moves), executed 22, against the 12 us the selection saves
+    // (profiles/r05_fine_histogram_score_kernel_variants.txt); on 10^6 three-variable candidates it costs 4 and saves 12.
+    constexpr bool PF = FUSE != 0 && K <= SDPCUT_PF_SCORE_MAXK;
     auto &pf_tab = S.pf_tab;
     if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
         if (threadIdx.x < 2) tk_cnt[threadIdx.x] = 0;
+        if constexpr (PF) {
 #pragma unroll
-        for (int j = 0; j < PF_BINS / 2 / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
+            for (int j = 0; j < PF_BINS / 2 / 256; ++j) pf_tab[threadIdx.x + 256 * j] = 0;
+        }
         __syncthreads();
     }
 
@@ -615,7 +625,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool viol = valid && lam < SDPCUT_NEG_EIGVAL;      // (only TK_MODE_FEAS ranks without the network)
                 const uint64_t key = key_of(-lam);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), viol);
-                if (viol) { const int f = pf_code(key, true); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
+                if (PF && viol) { const int f = pf_code(key, true); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }
                 c_viol += viol;
             }
             tail = tail || nx_tail; s0 = nx_s0; more = nx_more;
@@ -844,7 +854,7 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
                 const bool member = FUSE == TK_MODE_OPT ? valid : FUSE == TK_MODE_FEAS ? viol : (viol && pos);
                 const uint64_t key = key_of(FUSE == TK_MODE_FEAS ? -lam : obj);
                 hist_add_few(tk_hist, (uint32_t)(key >> 56), member);
-                if (member) { const int f = pf_code(key, FUSE == TK_MODE_FEAS); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
+                if (PF && member) { const int f = pf_code(key, FUSE == TK_MODE_FEAS); atomicAdd(&pf_tab[f >> 1], (f & 1) ? 0x10000u : 1u); }      // (LDS, no return value: one ds_add per candidate)
             }
         }
         wave_lds_sync();   // feat / ynn are rewritten by the next tile
@@ -883,7 +893,9 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
         if (tk_hist[threadIdx.x])
             __hip_atomic_fetch_add(&A.tk->hist_score[blockIdx.x % TK_SHREP][threadIdx.x], tk_hist[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-        if (A.pf_mloc > 0) pf_retire_table(A.tk, pf_tab, A.pf_mloc);      // (behind the barrier above: the table is complete)
+        if constexpr (PF) {
+            if (A.pf_mloc > 0) pf_retire_table(A.tk, pf_tab, A.pf_mloc);
+        }      // (behind the barrier above: the table is complete)
     }
 }
 
@@ -1284,9 +1296,9 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
 // variables and scores, and the head clusters: spar125-075-1 dim 4 has workgroups with > 18 of the 5000 (8 + 4 E failed there).
 // Reporting more costs little: ~45 atomics per workgroup over a few hundred addresses.  0: no fine histogram (option off, or
 // a table counter could overflow its 16 bits).
-static int pf_mloc_for(const sdpcut_ctx *h, const ScoreFuse *fuse, int64_t per_wg)
+static int pf_mloc_for(const sdpcut_ctx *h, const ScoreFuse *fuse, int64_t per_wg, int K)
 {
-    if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1) return 0;
+    if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1 || K > SDPCUT_PF_SCORE_MAXK) return 0;
     const double share = (double)fuse->k * (double)per_wg / (double)h->N;
     const double m = 24.0 + 8.0 * share;
     return m > 60000.0 ? 60000 : (int)(m + 0.999);
@@ -1328,8 +1340,9 @@ static int launch_score_k(sdpcut_ctx *h, uint32_t flags, hipEvent_t ev_start, hi
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
         set_balanced_tail(A, grid);
-        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
+        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid, K);
         A.spread = A.pf_mloc > 0 && b.n <= (int64_t)grid * 4 * A.strip;
+        if (A.tk && A.pf_mloc == 0) h->pf_counted = false;
         // (same arithmetic in every variant of one network: bit-equal scores)
 #define SCORE_MFMA_LAUNCH(F, C)                                                             \
     do {                                                                                    \
@@ -1406,8 +1419,9 @@ static int launch_classes_one(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fu
             grid = (int)(((b.n + 31) / 32 + 3) / 4);
         }
         set_balanced_tail(A, grid);
-        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid);
+        A.pf_mloc = pf_mloc_for(h, fuse, (b.n + grid - 1) / grid, k);
         A.spread = A.pf_mloc > 0 && b.n <= (int64_t)grid * 4 * A.strip;
+        if (A.tk && A.pf_mloc == 0) h->pf_counted = false;
         blocks += grid;
         AA.k[i] = k;
         AA.bend[i] = (int32_t)blocks;
@@ -1517,6 +1531,8 @@ static int calibrate_side_streams(sdpcut_ctx *h, uint32_t flags, int kbig)
 
 int launch_score(sdpcut_ctx *h, uint32_t flags, const ScoreFuse *fuse, bool *fused, int64_t *strong_out)
 {
+    // (r5) did EVERY launch of this round count the fine histogram of the selection's class?  (The selection reads the table only then.)
+    h->pf_counted = fuse != nullptr && fuse->k > 0;
     // the histograms are built by the MFMA kernel only: every non-empty size class must run on it
     if (fused) *fused = false;
     if (fuse) {

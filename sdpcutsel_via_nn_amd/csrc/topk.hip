@@ -1602,7 +1602,7 @@ static int topk_enqueue_after_pass0(sdpcut_ctx *h, TopkWs *ws, int mode, int64_t
             if (onfly)      // (a measure the mode does not use is never looked at: any readable array of n doubles will do)
                 hipLaunchKernelGGL(tk_refine_kernel<true>, dim3(grid), dim3(TK_THREADS), 0, h->stream, n, k, chunk, nullptr, ws,
                                    h->d_sel_key, h->d_sel_idx, mode, sel, eig ? eig : obj, obj ? obj : eig,
-                                   (int64_t)((h->prefilter && h->N >= SDPCUT_PF_MIN_N) ? k : 0), h->d_stats);
+                                   (int64_t)((h->prefilter && h->pf_counted && h->N >= SDPCUT_PF_MIN_N) ? k : 0), h->d_stats);
             else if (h->coop_launch)      // the runtime guarantees the co-residency (+20 us per launch)
                 HIP_TRY(h, hipLaunchCooperativeKernel((const void *)tk_refine_kernel<false>, dim3(grid), dim3(TK_THREADS), args, 0, h->stream));
             else
