@@ -461,9 +461,10 @@ __device__ __forceinline__ void tail_rows1(const double (&ts)[1][NT ? NT : 1], c
 constexpr int mfma_cols(int K) { return K == 2 ? SDPCUT_MFMA_J_K2 : K == 3 ? SDPCUT_MFMA_J_K3 : K == 4 ? SDPCUT_MFMA_J_K4 : SDPCUT_MFMA_J_K5; }
 
 // LDS of one workgroup of the MFMA kernel for size class K (a union of these serves the launch over all classes)
-#ifndef SDPCUT_PF_SCORE_MAXK
-#define SDPCUT_PF_SCORE_MAXK 3      // largest candidate size whose score kernel counts the fine histogram (0: none; see score_mfma_body)
+#ifndef SDPCUT_PF_SCORE_KMASK
+#define SDPCUT_PF_SCORE_KMASK (1 << 3)      // candidate sizes whose score kernel counts the fine histogram (bit k; 0: none; see score_mfma_body)
 #endif
+constexpr bool pf_score_k(int k) { return ((SDPCUT_PF_SCORE_KMASK >> k) & 1) != 0; }
 template <int K, int H, int NH>
 struct MfmaLds {
     static constexpr int S0 = (K + K * (K + 1) / 2 + 3) / 4;
@@ -477,7 +478,7 @@ struct MfmaLds {
     uint32_t tk_hist[256];       // leading-digit histogram of the selection that follows (A.tk != nullptr)
     uint32_t tk_cnt[2];
     uint32_t s_strong;
-    uint32_t pf_tab[K <= SDPCUT_PF_SCORE_MAXK ? PF_BINS / 2 : 1];    // (r5) the class members by window code, 16-bit counters, two per word (topk_dev.h)
+    uint32_t pf_tab[pf_score_k(K) ? PF_BINS / 2 : 1];    // (r5) the class members by window code, 16-bit counters, two per word (topk_dev.h)
 };
 
 // bid / nblk: this workgroup's index among the nblk workgroups that serve the class (blockIdx.x / gridDim.x of a launch over
@@ -571,11 +572,13 @@ __device__ __forceinline__ void score_mfma_body(const ScoreArgs A, MfmaLds<K, H,
     auto &tk_hist = S.tk_hist;
     auto &tk_cnt = S.tk_cnt;
     uint32_t c_viol = 0, c_pos = 0, c_strong = 0;     // per lane (vector registers: the scalar file is full)
-    // (r5) the fine histogram of the selection's class (topk_dev.h) is compiled into the kernels of 2- and 3-variable candidates only:
+    // (r5) the fine histogram of the selection's class (topk_dev.h) is compiled into the kernel of 3-variable candidates only:
     // merely present -- not executed -- it costs the 4-variable kernel 11 us on the 1.7e6-candidate cover of spar125-075-1 (240
     // registers, 112 bytes of scratch: the allocation of its hot loop moves), executed 22, against the 12 us the selection saves
-    // (profiles/r05_fine_histogram_score_kernel_variants.txt); on 10^6 three-variable candidates it costs 4 and saves 12.
-    constexpr bool PF = FUSE != 0 && K <= SDPCUT_PF_SCORE_MAXK;
+    // (profiles/r05_fine_histogram_score_kernel_variants.txt); the 2-variable kernel loses 7 us on 10^6 candidates the same way
+    // (profiles/r05_vs_r4_same_box.txt); on 10^6 three-variable candidates it costs 5-6 and saves 10.  Feasibility rounds -- three
+    // quarters of a BoxQP run -- count in the eigenvalue kernel (eig.hip) for every size.
+    constexpr bool PF = FUSE != 0 && pf_score_k(K);
     auto &pf_tab = S.pf_tab;
     if constexpr (FUSE != 0) {
         tk_hist[threadIdx.x] = 0;
@@ -1298,7 +1301,7 @@ static void set_balanced_tail(ScoreArgs &A, int grid)
 // a table counter could overflow its 16 bits).
 static int pf_mloc_for(const sdpcut_ctx *h, const ScoreFuse *fuse, int64_t per_wg, int K)
 {
-    if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1 || K > SDPCUT_PF_SCORE_MAXK) return 0;
+    if (!fuse || fuse->k <= 0 || per_wg >= 60000 || h->N < 1 || !pf_score_k(K)) return 0;
     const double share = (double)fuse->k * (double)per_wg / (double)h->N;
     const double m = 24.0 + 8.0 * share;
     return m > 60000.0 ? 60000 : (int)(m + 0.999);

@@ -178,9 +178,11 @@ def test_direct_selection_steps_aside_for_masses_of_equal_keys(golden_boxqp):
         sc.close()
 
 
-def test_direct_selection_on_a_real_mixed_cover(oracle):
-    """spar125-075-1 dim 4 (1 700 215 candidates of 2..4 variables, ONE launch over the three size classes) at recorded LP
-    points: combined round 4 (generic point) and feasibility round 8 -- both resolved directly, both identical to the passes."""
+def test_direct_selection_on_a_real_cover(oracle):
+    """spar125-075-1 dim 4 (1 700 215 four-variable candidates, enumerated index set by index set: the head clusters) at recorded
+    LP points: the feasibility round 8 is resolved from the fine histogram; the combined rounds 4 and 2 are not -- the score
+    kernel of 4-variable candidates does not count (csrc/score.hip: it costs that kernel more than the selection saves).  All
+    identical to the radix passes."""
     import os
     import sdpcutsel_via_nn_amd as pkg
     from conftest import GOLDEN
@@ -198,7 +200,6 @@ def test_direct_selection_on_a_real_mixed_cover(oracle):
             _same_round(a, b)
             assert np.array_equal(a["idx"], g["r%02d_ids" % r].astype(np.int64)) or r == 2
             print("round", r, "strategy", strat, "direct", taken, "fine bin / floor / members", _round_ab.last)
-            if r in (4, 8):
-                assert taken == 1, (r, strat, taken, _round_ab.last)
+            assert taken == (1 if r == 8 else 0), (r, strat, taken, _round_ab.last)
     finally:
         sc.close()
