@@ -187,6 +187,12 @@ __device__ __forceinline__ void pf_report(TopkWs *ws, int f, uint32_t count)
 // workgroup barrier; 256 threads).  Thread t owns bins 8 t .. 8 t + 7.  Reports every bin down to the one that holds the
 // workgroup's mloc-th largest member (fewer members than that: everything) and publishes that bin as its floor.  All four waves
 // work (a retiring workgroup holds its slot until its last wave is done: 40 instructions each beat 170 of one wave); two barriers.
+#ifndef SDPCUT_PF_NOINLINE
+#define SDPCUT_PF_NOINLINE 0
+#endif
+#if SDPCUT_PF_NOINLINE
+__attribute__((noinline))
+#endif
 static __device__ void pf_retire_table(TopkWs *ws, const uint32_t *tab, int mloc)
 {
     __shared__ uint32_t wtot[4];
