@@ -278,6 +278,8 @@ def bench_c3(device_index, steps, warm=20):
             ms.append(sc.last_timing()[0])
         sc.set_option(_capi.OPT_TIMING, 0)
         res["score_kernels_ms"] = float(np.mean(ms))
+        if strat == 4:      # the MLP FLOPs of the cover's candidates over the scoring launch (every candidate of this cover has 4 variables)
+            res["roofline_frac"] = FLOPS_PER_CAND[C3_DIM] * n / (res["score_kernels_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
         res["candidates_per_s_dropin"] = n / (res["dropin_pair_ms"] * 1e-3)
         out["strategy_%d" % strat] = res
     # (r4) the combined strategy at a GENERIC LP point as well (round 4 of the same trajectory): round 2 sits next to the McCormick
@@ -296,6 +298,14 @@ def bench_c3(device_index, steps, warm=20):
             torch.cuda.synchronize()
             res4[name + "_ms"] = (time.perf_counter() - t0) / steps * 1e3
             res4["cuts"] = cuts
+        sc.set_option(_capi.OPT_TIMING, 1)
+        ms = []
+        for _ in range(10):
+            fns["fused_csr"](4, vv4)
+            ms.append(sc.last_timing()[0])
+        sc.set_option(_capi.OPT_TIMING, 0)
+        res4["score_kernels_ms"] = float(np.mean(ms))
+        res4["roofline_frac"] = FLOPS_PER_CAND[C3_DIM] * n / (res4["score_kernels_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
         out["strategy_4_round_4_generic_point"] = res4
     sc.close()
     return out
@@ -677,11 +687,11 @@ def self_launch(n_ranks):
 
 # What a step should cost per rank at N = 8 (from the one-GPU phase measurements under profiles/): a SCALE
 # line is to be held against this.  us per phase; "step_ms" is their sum (the host's enqueue calls overlap the score kernel).
-EXPECTED_8GPU = {
-    "c2": {"score_and_head_us": 385, "all_gather_us": [20, 35], "merge_and_rows_us": [26, 30], "host_tail_us": 15,
-           "step_ms": [0.45, 0.48], "aggregate_candidates_per_s": [1.65e10, 1.75e10], "weak_scaling_efficiency": [0.87, 0.93]},
-    "c4": {"score_and_head_us": 4160, "selection_tail_point_and_collective_us": 200, "step_ms": [4.4, 4.5],
-           "strong_scaling_efficiency_vs_one_gpu_step": 0.95},
+EXPECTED_8GPU = {      # (r5: one source of truth -- DESIGN.md section 6 quotes THIS table; phases from profiles/r05_bench_forced_sharded.json, r05_bench_one_rank_rccl.json)
+    "c2": {"score_and_head_us": 350, "all_gather_us": [20, 35], "merge_and_rows_us": [25, 30], "host_tail_us": 15,
+           "step_ms": [0.41, 0.43], "aggregate_candidates_per_s": [1.86e10, 1.95e10], "weak_scaling_efficiency": [0.89, 0.93]},
+    "c4": {"score_and_head_us": 4060, "selection_tail_point_and_collective_us": 100, "step_ms": [4.15, 4.25],
+           "strong_scaling_efficiency_vs_one_gpu_step": 0.97},
 }
 
 
@@ -1001,13 +1011,19 @@ def main():
                                    "kernel_ms": r2["kernel_ms"], "roofline_frac": r2["frac"], "achieved_TFLOPs": r2["achieved"]}
                 s2.close()
             out["secondary"] = sec
+            for k2 in (2, 4, 5):
+                out["roofline"]["k%d_frac" % k2] = sec["k%d" % k2]["roofline_frac"]
             # the feasibility round (strategy 1, cut_select_qp.py:639-654) on the same list: the eigenvalue-only kernel
             out["eig_only"] = bench_eig_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
+            out["roofline"]["eig_only_ms_per_step"] = out["eig_only"]["ms_per_step"]
             out["secondary"]["strategy_2"] = bench_opt_only(make_scorer, K, n_local, vv_host, max(20, args.steps // 4), gpu_rounds)
             if not args.no_cold:
                 out["secondary"]["cold_round"] = bench_cold_round(make_scorer, K, n_local, vv_host)
             if not args.no_c3:
                 out["secondary"]["c3"] = bench_c3(local_rank, max(20, args.steps // 4))
+                # (scalars inside `roofline` survive the driver's record of the line: the lowest scoring kernel and the real-cover figures)
+                out["roofline"]["c3_round2_frac"] = out["secondary"]["c3"]["strategy_4"]["roofline_frac"]
+                out["roofline"]["c3_round4_frac"] = out["secondary"]["c3"].get("strategy_4_round_4_generic_point", {}).get("roofline_frac")
                 out["secondary"]["c5"] = bench_c5(local_rank, max(20, args.steps // 4))
                 out["secondary"]["mixed_cover"] = bench_mixed_cover(local_rank, max(50, args.steps // 2))
                 out["secondary"]["triangle"] = bench_triangle(local_rank, max(20, args.steps // 4))
