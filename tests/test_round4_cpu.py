@@ -175,12 +175,10 @@ def test_lambda_min_solver_on_exactly_singular_matrices(oracle):
 
 
 def test_exact_eigenvalue_tool_on_a_known_matrix():
-    """tools/lmin_truth.py (rational characteristic polynomial + 80-digit Newton): the noise-floor evidence rests on it"""
-    tools = os.path.join(ROOT, "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)
-    import lmin_truth
+    """tests/exact_eig.py (exact characteristic polynomial + 80-digit Newton; r4: tools/lmin_truth.py): the noise-floor evidence and
+    the per-pair proofs of the trajectory replay rest on it"""
+    import exact_eig
     A = np.array([[2.0, 1.0, 0.0], [1.0, 2.0, 1.0], [0.0, 1.0, 2.0]])          # eigenvalues 2 - sqrt 2, 2, 2 + sqrt 2
-    t = lmin_truth.exact_lambda_min(A, 0.5)
+    t = exact_eig.exact_lambda_min(A, 0.5)
     from decimal import Decimal
     assert abs(t - (Decimal(2) - Decimal(2).sqrt())) < Decimal(10) ** -50
