@@ -96,11 +96,12 @@ enum { SDPCUT_KERNEL_MFMA = 0, SDPCUT_KERNEL_SIMPLE = 1, SDPCUT_KERNEL_VALU = 2 
  * whose list is SHORT and whose rounds run next to another handle's (the QCQP round's objective cover beside its constraints
  * cover, sdpcut_round_csr_begin): its few small kernels are then dispatched ahead of the other list's waiting workgroups instead of
  * behind them.  Not allowed while a round is pending; ignored by a handle that runs on a caller's stream (sdpcut_set_stream). */
-/* SDPCUT_OPT_PREFILTER (default 1; needs SDPCUT_OPT_FUSE_KEYS): the score / eigenvalue kernels of a fused round also count the class
- * members by the top sixteen bits of their selection keys (a 1024-bin window; one LDS atomic per candidate, reported when a
- * workgroup retires, only from the current lower bound of the k-th largest key upwards).  The selection then resolves two digits
- * without reading a key and compacts the head's superset in one pass without grid barriers.  0: the radix passes of rounds 2-4
- * (A/B; identical results). */
+/* SDPCUT_OPT_PREFILTER (default 1; needs SDPCUT_OPT_FUSE_KEYS): the eigenvalue kernel (every class) and the score kernel (3-variable
+ * classes) of a fused round also count the class members in a 2048-bin window over the top seventeen bits of their selection keys
+ * (csrc/topk_dev.h: one LDS atomic per candidate; a workgroup reports, when it retires, only the bins down to the one that holds
+ * its own m-th largest member, and publishes that floor).  Where the bin of the k-th largest key lies above every floor and its
+ * members fit the sort buffers, the selection is resolved from the table: one pass over the scores, no digit pass, no grid barrier.
+ * 0: the radix passes of rounds 2-4 (A/B; identical results). */
 enum { SDPCUT_OPT_KERNEL = 1, SDPCUT_OPT_TIMING = 2, SDPCUT_OPT_FUSE_KEYS = 3, SDPCUT_OPT_AUTO_REGIME = 4,
        SDPCUT_OPT_FUSED_TAIL = 5, SDPCUT_OPT_COOP_LAUNCH = 6, SDPCUT_OPT_EIG_KERNEL = 7, SDPCUT_OPT_STREAM_PRIORITY = 8,
        SDPCUT_OPT_SIDE_STREAMS = 9, SDPCUT_OPT_ONE_LAUNCH = 10, SDPCUT_OPT_PREFILTER = 11 };
