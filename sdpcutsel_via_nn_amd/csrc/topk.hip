@@ -210,20 +210,44 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
             if ((threadIdx.x & 63) < PF_FLOOR_REP) pf_fl = ws->pf_floor[threadIdx.x & 63][0];
         }
         if (lo < hi) {
+            // (r5) only the measure the mode ranks by: a feasibility / optimality selection reads 8 bytes per candidate, not 16 -- the
+            // scan of the scores is what this kernel waits for longest (phase stamps: table 3.2 us, scores 3.5-4.3 more)
+            const double *m0 = mode == TK_MODE_OPT ? obj : eig;
+            const bool two = mode != TK_MODE_OPT && mode != TK_MODE_FEAS;      // uniform
 #pragma unroll
             for (int u = 0; u < TK_UNROLL; ++u) {
                 const int64_t i = lo + (int64_t)u * TK_THREADS + threadIdx.x;
                 const int64_t ic = i < hi ? i : hi - 1;
-                pre_e[u] = eig[ic];
-                pre_o[u] = obj[ic];
+                pre_e[u] = m0[ic];
+            }
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) {
+                    const int64_t i = lo + (int64_t)u * TK_THREADS + threadIdx.x;
+                    const int64_t ic = i < hi ? i : hi - 1;
+                    pre_o[u] = obj[ic];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TK_UNROLL; ++u) pre_o[u] = pre_e[u];      // (masked_key looks at one of the two)
             }
             if (pf_k > 0 && use_cache) {      // uniform: the direct path reads its whole chunk (<= 4096 scores) without a second round trip
 #pragma unroll
                 for (int u = 0; u < TK_UNROLL; ++u) {
                     const int64_t i = lo + (int64_t)(TK_UNROLL + u) * TK_THREADS + threadIdx.x;
                     const int64_t ic = i < hi ? i : hi - 1;
-                    pre_e2[u] = eig[ic];
-                    pre_o2[u] = obj[ic];
+                    pre_e2[u] = m0[ic];
+                }
+                if (two) {
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) {
+                        const int64_t i = lo + (int64_t)(TK_UNROLL + u) * TK_THREADS + threadIdx.x;
+                        const int64_t ic = i < hi ? i : hi - 1;
+                        pre_o2[u] = obj[ic];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < TK_UNROLL; ++u) pre_o2[u] = pre_e2[u];
                 }
             }
         }
@@ -318,6 +342,60 @@ __global__ __launch_bounds__(TK_THREADS) void tk_refine_kernel(int64_t n, int64_
         __syncthreads();
     }
     TkState st;
+    if constexpr (ONFLY) {
+        if (direct && use_cache) {      // uniform over the grid
+            // ---- (r5) the whole chunk is the two batches requested at the top of the kernel: keys and membership stay in registers,
+            // ONE scan over the workgroup gives every thread its offset and the workgroup its count, one returning atomic reserves the
+            // slice, the members are written.  (The general path below counts, reserves, then re-reads its keys row by row with an
+            // LDS atomic per row: 16 dependent LDS round trips, 2.5 us of this kernel's 15 by its phase stamps.)
+            const uint64_t T0 = st1.prefix;
+            const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            uint64_t dk[2 * TK_UNROLL];
+            uint32_t mask = 0;
+#pragma unroll
+            for (int u = 0; u < 2 * TK_UNROLL; ++u) {
+                const int64_t i = lo + (int64_t)u * TK_THREADS + threadIdx.x;
+                const bool in = i < hi;
+                dk[u] = in ? masked_key(mode, u < TK_UNROLL ? pre_e[u % TK_UNROLL] : pre_e2[u % TK_UNROLL],
+                                        u < TK_UNROLL ? pre_o[u % TK_UNROLL] : pre_o2[u % TK_UNROLL]) : 0ull;
+                mask |= (uint32_t)(in && dk[u] >= T0) << u;
+            }
+            const uint32_t cnt = (uint32_t)__popc(mask);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if (ln >= off) incl += o;
+            }
+            if (ln == 63) wave_cnt[wv] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < TK_THREADS / 64; ++w) {
+                if (w < wv) wbase += wave_cnt[w];
+                total += wave_cnt[w];
+            }
+            if (total == 0) return;      // uniform per workgroup
+            if (threadIdx.x == 0)
+                slice = __hip_atomic_fetch_add((unsigned long long *)&ws->n_sel, (unsigned long long)total, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            int64_t slot = (int64_t)slice + wbase + incl - cnt;
+#pragma unroll
+            for (int u = 0; u < 2 * TK_UNROLL; ++u) {
+                if ((mask >> u) & 1u) {
+                    if (slot < (int64_t)TK_MAXK) {
+                        sel_key[slot] = dk[u];
+                        sel_idx[slot] = (uint32_t)(lo + (int64_t)u * TK_THREADS + threadIdx.x);
+                    } else {
+                        st_i64(&ws->counters[4], 1);      // cannot happen (the table is exact from e* up): the selection is void, the host's general path answers
+                    }
+                    ++slot;
+                }
+            }
+            return;
+        }
+    }
     if (direct) {
         // ---- one pass: the keys of this chunk (into the LDS cache when they fit), how many of them lie at or above the edge
         st = st1;

@@ -1,6 +1,6 @@
 set -o pipefail
 export TMPDIR=/tmp
-# the sort tail of a selection (merge ranks: four searches side by side, all tile loads in flight): parity, then bench + kernel timeline on the same box
+# the selection tail (refine, tile sort, merge ranks): parity, then bench + kernel timeline on the same box
 timeout -k 10 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_parity.py tests/test_gpu_round4.py -m gpu -x -q > gpurun_out/r05_sorttail_tests.txt 2>&1 || { tail -30 gpurun_out/r05_sorttail_tests.txt; exit 1; }
 tail -2 gpurun_out/r05_sorttail_tests.txt
 for i in 1 2; do
