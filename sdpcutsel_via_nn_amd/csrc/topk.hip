@@ -870,19 +870,19 @@ __device__ __forceinline__ void mergerank_body(int64_t base, double score_add, c
     const int n_sel = (int)ws->n_sel, k_eff = (int)ws->counters[3];
     if (blockIdx.x * TK_THREADS >= n_sel) return;   // uniform
     const int ntiles = (n_sel + TK_TILE - 1) / TK_TILE;
-    // (a head of 5000: 11 tiles, 22 entries per thread -- two batches; each batch is a round trip to L2)
-    for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 16 * TK_THREADS) {      // 16 pairs in flight per thread
-        uint64_t kk[16];
-        uint32_t ii[16];
+    // (a head of 5000: 11 tiles, 22 entries per thread; each batch is a round trip to L2)
+    for (int j0 = 0; j0 < ntiles * TK_TILE; j0 += 24 * TK_THREADS) {      // 24 pairs in flight per thread: 12 tiles in ONE trip to L2
+        uint64_t kk[24];
+        uint32_t ii[24];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 24; ++u) {
             const int j = j0 + u * TK_THREADS + threadIdx.x;
             const bool in = j < ntiles * TK_TILE;
             kk[u] = in ? tile_key[j] : 0ull;
             ii[u] = in ? tile_idx[j] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 24; ++u) {
             const int j = j0 + u * TK_THREADS + threadIdx.x;
             if (j < ntiles * TK_TILE) { sk[j] = kk[u]; si[j] = ii[u]; }
         }
@@ -900,29 +900,41 @@ __device__ __forceinline__ void mergerank_body(int64_t base, double score_add, c
     // a third of this kernel's time (11.6 -> 8.8 us).  Steps 256, 128 .. 1 count the entries below e among the first 511 of a
     // tile, one more comparison settles the 512-th.
     constexpr int MR_T = 4;
-    for (int t0 = 0; t0 < ntiles; t0 += MR_T) {
-        int tb[MR_T], pos[MR_T];
-        bool act[MR_T];
+    // (the searches are bound by the LDS's throughput for scattered reads -- 8 or 16 at a time are no faster than 4, and they take
+    // as long as the number of tiles searched says -- so e's own tile and tiles that do not exist are not searched: the other
+    // ntiles - 1 tiles in batches of four, the last batch with its own trip count; branch-free inside a batch)
+    auto search = [&](auto live_tag, const int t0) __attribute__((always_inline)) {
+        constexpr int LIVE = decltype(live_tag)::value;
+        int tb[LIVE], pos[LIVE];
 #pragma unroll
-        for (int u = 0; u < MR_T; ++u) {
-            act[u] = t0 + u < ntiles && t0 + u != te;
-            tb[u] = (act[u] ? t0 + u : te) * TK_TILE;      // (an idle slot searches e's own tile: readable, result dropped)
+        for (int u = 0; u < LIVE; ++u) {
+            const int o = t0 + u;                    // the o-th OTHER tile
+            tb[u] = (o < te ? o : o + 1) * TK_TILE;
             pos[u] = 0;
         }
 #pragma unroll
         for (int step = TK_TILE / 2; step >= 1; step >>= 1) {
-            uint64_t km[MR_T];
-            uint32_t im[MR_T];
+            uint64_t km[LIVE];
+            uint32_t im[LIVE];
 #pragma unroll
-            for (int u = 0; u < MR_T; ++u) { km[u] = sk[tb[u] + pos[u] + step - 1]; im[u] = si[tb[u] + pos[u] + step - 1]; }
+            for (int u = 0; u < LIVE; ++u) { km[u] = sk[tb[u] + pos[u] + step - 1]; im[u] = si[tb[u] + pos[u] + step - 1]; }
 #pragma unroll
-            for (int u = 0; u < MR_T; ++u) pos[u] += comp_less<TIE>(km[u], im[u], ke, ie, obj) ? step : 0;
+            for (int u = 0; u < LIVE; ++u) pos[u] += comp_less<TIE>(km[u], im[u], ke, ie, obj) ? step : 0;
         }
 #pragma unroll
-        for (int u = 0; u < MR_T; ++u) {
+        for (int u = 0; u < LIVE; ++u) {
             const bool last = pos[u] == TK_TILE - 1 && comp_less<TIE>(sk[tb[u] + TK_TILE - 1], si[tb[u] + TK_TILE - 1], ke, ie, obj);
-            rank += act[u] ? pos[u] + (last ? 1 : 0) : 0;
+            rank += pos[u] + (last ? 1 : 0);
         }
+    };
+    const int others = ntiles - 1;      // uniform per workgroup
+    int t0 = 0;
+    for (; t0 + MR_T <= others; t0 += MR_T) search(std::integral_constant<int, MR_T>{}, t0);
+    switch (others - t0) {
+    case 3: search(std::integral_constant<int, 3>{}, t0); break;
+    case 2: search(std::integral_constant<int, 2>{}, t0); break;
+    case 1: search(std::integral_constant<int, 1>{}, t0); break;
+    default: break;
     }
     if (rank >= k_eff) return;                                // superset entries beyond the head
     idx_out[rank] = base + (int64_t)ie;
