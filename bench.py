@@ -688,8 +688,8 @@ def self_launch(n_ranks):
 # What a step should cost per rank at N = 8 (from the one-GPU phase measurements under profiles/): a SCALE
 # line is to be held against this.  us per phase; "step_ms" is their sum (the host's enqueue calls overlap the score kernel).
 EXPECTED_8GPU = {      # (r5: one source of truth -- DESIGN.md section 6 quotes THIS table; phases from profiles/r05_bench_forced_sharded.json, r05_bench_one_rank_rccl.json)
-    "c2": {"score_and_head_us": 350, "all_gather_us": [20, 35], "merge_and_rows_us": [25, 30], "host_tail_us": 15,
-           "step_ms": [0.41, 0.43], "aggregate_candidates_per_s": [1.86e10, 1.95e10], "weak_scaling_efficiency": [0.89, 0.93]},
+    "c2": {"score_and_head_us": 345, "all_gather_us": [20, 35], "merge_and_rows_us": [25, 30], "host_tail_us": 15,
+           "step_ms": [0.40, 0.43], "aggregate_candidates_per_s": [1.86e10, 2.0e10], "weak_scaling_efficiency": [0.88, 0.94]},
     "c4": {"score_and_head_us": 4060, "selection_tail_point_and_collective_us": 100, "step_ms": [4.15, 4.25],
            "strong_scaling_efficiency_vs_one_gpu_step": 0.97},
 }
