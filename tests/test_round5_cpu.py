@@ -128,3 +128,32 @@ def test_fine_histogram_window_arithmetic():
             assert k >= edge(c, feas) and (c == PF - 1 or k < edge(c + 1, feas))
     assert 0 < code(1e-15, True) < code(8.0, True) < PF - 1                  # the whole range of a feasibility score inside the window
     assert code(-1.0, False) < PF // 2 <= code(0.0, False) < code(1.0, False)
+
+
+def test_fixed_step_lower_bound_of_the_merge_ranks():
+    """numpy twin of the branch-free search of csrc/topk.hip (mergerank_body): steps 256, 128 .. 1 over the first 511 entries of a
+    sorted tile of 512, one more comparison for the 512-th, give the number of entries below e -- for every position of e,
+    including below the first and above the last entry -- and the ranks of all entries of several tiles, each counted in its own
+    tile by position and in the others by this search, are a permutation."""
+    rng = np.random.default_rng(3)
+    tile = np.sort(rng.choice(10 ** 6, size=512, replace=False))
+
+    def lower_bound(t, e):
+        pos = 0
+        step = 256
+        while step >= 1:
+            pos += step if t[pos + step - 1] < e else 0
+            step >>= 1
+        assert pos <= 511
+        return pos + (1 if pos == 511 and t[511] < e else 0)
+    for e in list(tile[:5]) + list(tile[-5:]) + [-1, 10 ** 7] + list(rng.integers(0, 10 ** 6, size=300)):
+        assert lower_bound(tile, e) == int(np.searchsorted(tile, e, side="left"))
+    vals = rng.permutation(5 * 512 + 100)[:5 * 512]
+    tiles = [np.sort(vals[i * 512:(i + 1) * 512]) for i in range(5)]
+    ranks = []
+    for ti, t in enumerate(tiles):
+        for p, e in enumerate(t):
+            ranks.append(p + sum(lower_bound(o, e) for oi, o in enumerate(tiles) if oi != ti))
+    assert sorted(ranks) == list(range(5 * 512))
+    order = np.argsort(np.concatenate(tiles), kind="stable")
+    assert np.array_equal(np.argsort(np.asarray(ranks), kind="stable"), order)
